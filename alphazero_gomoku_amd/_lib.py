@@ -1,0 +1,81 @@
+"""ctypes binding of libazgomoku.so (include/azgomoku.h).  There is no CPU fallback:
+if the HIP library is missing or a call fails, an exception is raised."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libazgomoku.so")
+
+PRIOR_NET, PRIOR_UNIFORM32, PRIOR_HASH = 0, 1, 2
+LAYOUT_TORCH, LAYOUT_THEANO = 0, 1
+
+ERROR_NAMES = {-1: "AZG_EINVAL", -2: "AZG_EHIP", -3: "AZG_ENOWEIGHTS", -4: "AZG_EARENA",
+               -5: "AZG_ESTATE", -6: "AZG_EMOVE"}
+
+# every symbol include/azgomoku.h declares
+SYMBOLS = ["azg_create", "azg_destroy", "azg_last_error", "azg_set_weights", "azg_reset_games",
+           "azg_set_position", "azg_search", "azg_root_stats", "azg_sample_and_advance",
+           "azg_advance", "azg_update_with_move", "azg_status", "azg_states",
+           "azg_drain_samples", "azg_eval_batch", "azg_board_step_batch", "azg_profile",
+           "azg_stream"]
+
+
+class AzgError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__("%s (%d): %s" % (ERROR_NAMES.get(code, "AZG_E?"), code, message))
+        self.code = code
+
+
+class Config(C.Structure):
+    _fields_ = [("board_n", C.c_int32), ("n_in_row", C.c_int32), ("n_playout", C.c_int32),
+                ("n_games", C.c_int32), ("c_puct", C.c_double), ("device", C.c_int32),
+                ("prior_mode", C.c_int32), ("arena_nodes", C.c_int32), ("reserved", C.c_int32)]
+
+
+_lib = None
+
+
+def load():
+    """Load the shared library (raises if it was not built)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "libazgomoku.so not found at %s: build it with alphazero_gomoku_amd/csrc/build.sh "
+            "(hipcc --offload-arch=gfx950); this package has no CPU fallback" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, i32p, f32p, f64p = C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_float), C.POINTER(C.c_double)
+    u8p, i8p, u64p, i64p = C.POINTER(C.c_uint8), C.POINTER(C.c_int8), C.POINTER(C.c_uint64), C.POINTER(C.c_int64)
+    L.azg_create.argtypes = [C.POINTER(Config), C.POINTER(vp)]
+    L.azg_destroy.argtypes = [vp]
+    L.azg_destroy.restype = None
+    L.azg_last_error.argtypes = [vp]
+    L.azg_last_error.restype = C.c_char_p
+    L.azg_set_weights.argtypes = [vp, C.POINTER(vp), C.c_int]
+    L.azg_reset_games.argtypes = [vp, u8p, C.POINTER(C.c_uint32), i64p]
+    L.azg_set_position.argtypes = [vp, C.c_int, u64p, u64p, C.c_int, C.c_int]
+    L.azg_search.argtypes = [vp]
+    L.azg_root_stats.argtypes = [vp, vp, vp, vp, vp]
+    L.azg_sample_and_advance.argtypes = [vp, C.c_double, i32p, f64p]
+    L.azg_advance.argtypes = [vp, i32p, C.c_int, C.c_double]
+    L.azg_update_with_move.argtypes = [vp, i32p]
+    L.azg_status.argtypes = [vp, u8p, i8p, i32p]
+    L.azg_states.argtypes = [vp, vp]
+    L.azg_drain_samples.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, C.POINTER(C.c_int)]
+    L.azg_eval_batch.argtypes = [vp, vp, C.c_int, vp, vp]
+    L.azg_board_step_batch.argtypes = [vp, C.c_int, u64p, i32p, i32p, i32p, i32p, u8p, i8p, f32p]
+    L.azg_profile.argtypes = [vp, i64p, f64p, i64p]
+    L.azg_stream.argtypes = [vp]
+    L.azg_stream.restype = vp
+    for name in SYMBOLS:
+        if name not in ("azg_destroy", "azg_last_error", "azg_stream"):
+            getattr(L, name).restype = C.c_int
+    _lib = L
+    return L
+
+
+def check(handle, rc):
+    if rc != 0:
+        msg = load().azg_last_error(handle)
+        raise AzgError(rc, msg.decode() if msg else "")

@@ -1,0 +1,66 @@
+// Shared host/device definitions of the self-play engine (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace azg {
+
+constexpr int MAXW = 4;            // 64-bit words per colour (boards up to 16x16 = 256 cells)
+constexpr int MAXS = 256;
+constexpr int WAVE = 64;
+
+// Edge meta word: action (cell id) in the low 16 bits, number of children in the high 16.
+__host__ __device__ inline unsigned meta_pack(int act, int k) { return (unsigned)act | ((unsigned)k << 16); }
+__host__ __device__ inline int meta_act(unsigned m) { return (int)(m & 0xFFFFu); }
+__host__ __device__ inline int meta_k(unsigned m) { return (int)(m >> 16); }
+
+// Packed CNN weights (engine-owned copy, float32).  Conv kernels are stored per
+// 32-output-channel tile and k-step so that one wave reads 64 consecutive floats
+// per MFMA A operand: wconv[l][(cotile*KS + kstep)*64 + lane] =
+// W[co = cotile*32 + (lane&31)][ci = 2*(kstep/9) + (lane>>5)][tap = kstep%9].
+struct NetWeights {
+    const float *wconv[3];   // packed conv1..conv3
+    const float *bconv[3];   // biases [32],[64],[128]
+    const float *whead;      // [6][128]: rows 0-3 act_conv1, rows 4-5 val_conv1
+    const float *bhead;      // [6]
+    const float *wpfc;       // act_fc1 transposed: [4S][S]
+    const float *bpfc;       // [S]
+    const float *wvfc1;      // val_fc1 transposed: [2S][64]
+    const float *bvfc1;      // [64]
+    const float *wvfc2;      // [64]
+    const float *bvfc2;      // [1]
+};
+
+// Everything the kernels need, passed by value.
+struct DevState {
+    int N, S, NW, n_in_row, B, cap, prior_mode, n_playout;
+    double c_puct;
+    // live boards: stones of player 1 / player 2 as bit sets
+    unsigned long long *bb;        // [B][2][MAXW]
+    int *ply;                      // [B] len(states)
+    int *last_move;                // [B]
+    int *first_player;             // [B] player (1/2) who moves at even ply
+    signed char *status;           // [B] 0 live, 1 ended, 2 idle (never started)
+    signed char *winner;           // [B] 1, 2, -1
+    int *err;                      // [B] sticky error bits (1 = arena overflow)
+    // search trees: two arenas per game, the live one selected by cur[g]
+    float *eP;                     // [B][2][cap] prior
+    int *eN;                       // [B][2][cap] visits
+    double *eQ;                    // [B][2][cap] mean value
+    int *eChild;                   // [B][2][cap] first child edge or -1
+    unsigned *eMeta;               // [B][2][cap] action | children << 16
+    int *used;                     // [B] edges in use in the live arena
+    unsigned char *cur;            // [B]
+    long long *evals;              // [B] leaf evaluations that needed priors (profiling)
+    // per-game training samples of the game in progress
+    unsigned long long *s_bb;      // [B][S][2][MAXW] stones before the move
+    int *s_last;                   // [B][S] last_move before the move
+    int *s_ply;                    // [B][S] len(states) before the move
+    double *s_pi;                  // [B][S][S]
+    int *s_count;                  // [B] samples recorded (= plies played by the engine)
+    long long *game_id;            // [B]
+    unsigned char *drained;        // [B]
+    NetWeights net;
+};
+
+}  // namespace azg

@@ -1,0 +1,479 @@
+// Kernels of the self-play engine (gfx950).  One game per wave for all tree and board
+// work; the search kernel keeps T games per 256-thread workgroup and runs a whole
+// move's n_playout playouts in one launch with no inter-workgroup communication.
+#pragma once
+#include "azg_cnn.hpp"
+#include "azg_tree.hpp"
+
+namespace azg {
+
+// The fence that orders one lane's global stores before other lanes' later loads of the
+// same wave/workgroup (same CU, write-through L1).
+__device__ inline void wg_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }
+
+// ---------------------------------------------------------------- search
+// MCTS.get_move_probs' playout loop (mcts_alphaZero.py:161-163) for T games.
+// MODE: AZG_PRIOR_NET (0), UNIFORM32 (1), HASH (2).
+template <int N, int T, int MODE>
+__global__ __launch_bounds__(256) void search_kernel(DevState st)
+{
+    using G = CnnGeom<(MODE == 0 ? N : 4), (MODE == 0 ? T : 1)>;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    GameLds *gls = reinterpret_cast<GameLds *>(smem + (MODE == 0 ? G::END : 0));
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const bool tree_wave = wave < T;
+    const int g = blockIdx.x * T + wave;
+    GameLds *gl = &gls[tree_wave ? wave : 0];
+
+    if (tree_wave) {
+        const bool live = (g < st.B) && st.status[g] == 0;
+        if (live && lane < 2 * MAXW) ((u64 *)gl->root_bb)[lane] = st.bb[(size_t)g * 2 * MAXW + lane];
+        if (lane == 0) {
+            gl->live = live;
+            gl->need_eval = 0;
+            gl->term = 0;
+            gl->gid = g;
+            if (live) {
+                gl->root_ply = st.ply[g];
+                gl->root_last = st.last_move[g];
+                gl->first_player = st.first_player[g];
+            }
+        }
+    }
+    __syncthreads();
+    bool any_live = false;
+#pragma unroll
+    for (int t = 0; t < T; t++) any_live |= gls[t].live != 0;
+    if (!any_live) return;
+    if (MODE == 0) cnn_prepare<G>(st.net, smem);
+
+    const bool active = tree_wave && gl->live;
+    TreeView tv;
+    int first_player = 1;
+    if (active) { tv = tree_view(st, g, st.cur[g]); first_player = gl->first_player; }
+    long long n_eval = 0;
+
+    for (int it = 0; it < st.n_playout; it++) {
+        Descent d = {0, 0, 0, 0};
+        int term = 0;
+        if (active) {
+            d = wave_select(st, tv, gl, lane);
+            term = wave_game_end(gl->leaf_bb, st.N, st.S, st.n_in_row, d.ply, lane);
+            if (lane == 0) { gl->term = term; gl->need_eval = term == 0; }
+            n_eval += term == 0;
+        }
+        if (MODE == 0) {
+            __syncthreads();
+            bool any = false;
+#pragma unroll
+            for (int t = 0; t < T; t++) any |= gls[t].live && gls[t].need_eval;
+            if (any) {
+                cnn_forward<G>(st.net, smem, [&](int leaf, int pl, int row, int col) -> float {
+                    const GameLds *q = &gls[leaf];
+                    if (!q->live) return 0.0f;
+                    return plane_value(q->leaf_bb, N, q->leaf_ply, q->leaf_last,
+                                       player_at(q->first_player, q->leaf_ply), pl, row, col);
+                });
+            } else {
+                __syncthreads();
+            }
+        }
+        if (active) {
+            const int cur_player = player_at(first_player, d.ply);
+            double v;
+            if (term) {
+                // mcts_alphaZero.py:139-145: tie 0, else +1 if the winner is to move, else -1
+                v = term == 3 ? 0.0 : (term == cur_player ? 1.0 : -1.0);
+            } else if (MODE == 0) {
+                const float *probs = smem + G::LG_OFF + wave * G::S;
+                wave_expand(st, tv, gl, d, g, lane, [=](int c) { return probs[c]; });
+                v = (double)smem[G::VAL_OFF + wave];
+            } else if (MODE == 1) {
+                const float p = 1.0f / (float)(st.S - d.ply);
+                wave_expand(st, tv, gl, d, g, lane, [=](int) { return p; });
+                v = 0.0;
+            } else {
+                const u64 key = state_key(gl->leaf_bb, st.NW, cur_player);
+                wave_expand(st, tv, gl, d, g, lane, [=](int c) { return hash_prior(key, c); });
+                v = hash_value(key);
+            }
+            wave_backup(tv, gl, d.depth, v, lane);
+            wg_fence();
+        }
+    }
+    if (active && lane == 0) st.evals[g] += n_eval;
+}
+
+// ---------------------------------------------------------------- eval_batch
+// PolicyValueNet.policy_value (policy_value_net_pytorch.py:80-94) on n states.
+template <int N, int T>
+__global__ __launch_bounds__(256) void eval_kernel(NetWeights nw, const float *states, int n,
+                                                   float *probs, float *values)
+{
+    using G = CnnGeom<N, T>;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int n0 = blockIdx.x * T;
+    cnn_prepare<G>(nw, smem);
+    cnn_forward<G>(nw, smem, [&](int leaf, int pl, int row, int col) -> float {
+        const int i = n0 + leaf;
+        return i < n ? states[((size_t)i * 4 + pl) * G::S + row * N + col] : 0.0f;
+    });
+    for (int idx = threadIdx.x; idx < T * G::S; idx += 256) {
+        const int leaf = idx / G::S;
+        if (n0 + leaf < n) probs[(size_t)n0 * G::S + idx] = smem[G::LG_OFF + idx];
+    }
+    if (threadIdx.x < T && n0 + threadIdx.x < n) values[n0 + threadIdx.x] = smem[G::VAL_OFF + threadIdx.x];
+}
+
+// ---------------------------------------------------------------- numpy-order sums
+// numpy's add.reduce over a contiguous float64 vector (pairwise, 8 partial sums per
+// block of at most 128), as used by np.sum in mcts_alphaZero.py:18.
+__device__ inline double np_block_sum(const double *a, int n)
+{
+    if (n < 8) {
+        double res = 0.0;
+        for (int i = 0; i < n; i++) res += a[i];
+        return res;
+    }
+    double r0 = a[0], r1 = a[1], r2 = a[2], r3 = a[3], r4 = a[4], r5 = a[5], r6 = a[6], r7 = a[7];
+    int i;
+    for (i = 8; i < n - (n % 8); i += 8) {
+        r0 += a[i]; r1 += a[i + 1]; r2 += a[i + 2]; r3 += a[i + 3];
+        r4 += a[i + 4]; r5 += a[i + 5]; r6 += a[i + 6]; r7 += a[i + 7];
+    }
+    double res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
+    for (; i < n; i++) res += a[i];
+    return res;
+}
+__device__ inline double np_sum_l1(const double *a, int n)
+{
+    if (n <= 128) return np_block_sum(a, n);
+    int n2 = n / 2;
+    n2 -= n2 % 8;
+    return np_block_sum(a, n2) + np_block_sum(a + n2, n - n2);
+}
+__device__ inline double np_sum(const double *a, int n)   // n <= 256
+{
+    if (n <= 128) return np_block_sum(a, n);
+    int n2 = n / 2;
+    n2 -= n2 % 8;
+    return np_sum_l1(a, n2) + np_sum_l1(a + n2, n - n2);
+}
+
+// ---------------------------------------------------------------- advance
+enum { ADV_SAMPLE = 1, ADV_RECORD = 2, ADV_BOARD = 4, ADV_REROOT = 8 };
+
+// Start a fresh root (TreeNode(None, 1.0), mcts_alphaZero.py:108,192) in arena `arena`.
+__device__ inline void fresh_root(const DevState &st, int g, int arena)
+{
+    TreeView t = tree_view(st, g, arena);
+    t.P[0] = 1.0f; t.N[0] = 0; t.Q[0] = 0.0; t.child[0] = -1; t.meta[0] = meta_pack(0xFFFF, 0);
+    st.used[g] = 1;
+    st.cur[g] = (unsigned char)arena;
+}
+
+// MCTS.update_with_move (mcts_alphaZero.py:183-192): the subtree below child edge
+// `c` of the old arena becomes the whole tree of the new arena.  Breadth-first copy;
+// an edge's child field holds the OLD block address until the scan reaches it.
+__device__ inline void wave_reroot(const DevState &st, int g, int c, int lane)
+{
+    const int oa = st.cur[g], na = oa ^ 1;
+    const TreeView o = tree_view(st, g, oa), n = tree_view(st, g, na);
+    if (lane == 0) {
+        n.P[0] = o.P[c]; n.N[0] = o.N[c]; n.Q[0] = o.Q[c]; n.child[0] = o.child[c]; n.meta[0] = o.meta[c];
+    }
+    wg_fence();
+    int freep = 1, scan = 0;
+    while (scan < freep) {
+        const int chunk_end = min(scan + WAVE, freep);
+        const int e = scan + lane;
+        int oc = -1, k = 0;
+        if (e < chunk_end) { oc = n.child[e]; k = meta_k(n.meta[e]); }
+        u64 m = __ballot(oc >= 0);
+        while (m) {
+            const int l = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            const int ob = __shfl(oc, l), kk = __shfl(k, l);
+            for (int i = lane; i < kk; i += WAVE) {
+                n.P[freep + i] = o.P[ob + i];
+                n.N[freep + i] = o.N[ob + i];
+                n.Q[freep + i] = o.Q[ob + i];
+                n.child[freep + i] = o.child[ob + i];
+                n.meta[freep + i] = o.meta[ob + i];
+            }
+            if (lane == 0) n.child[scan + l] = freep;
+            freep += kk;
+        }
+        wg_fence();
+        scan = chunk_end;
+    }
+    if (lane == 0) { st.used[g] = freep; st.cur[g] = (unsigned char)na; }
+}
+
+// MCTSPlayer.get_action's tail (mcts_alphaZero.py:216-242) + Game.start_self_play's
+// bookkeeping (game.py:381-391) for one game per wave.  noise: [B][S] Dirichlet draws
+// in child order, u01: [B] uniforms (both from the game's numpy-legacy stream).
+__global__ __launch_bounds__(256) void advance_kernel(DevState st, double temp, const double *noise,
+                                                      const double *u01, const int *given, int flags,
+                                                      int *moves_out, double *pi_out)
+{
+    __shared__ double s_e[4][MAXS];
+    __shared__ double s_c[4][MAXS];
+    __shared__ u64 s_bbw[4][2][MAXW];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int g = blockIdx.x * 4 + wave;
+    if (g >= st.B) return;
+    int move = -1;
+    const bool live = st.status[g] == 0;
+    const bool want = live && ((flags & ADV_SAMPLE) || (given && given[g] >= 0));
+    if (!want) {
+        if (moves_out && lane == 0) moves_out[g] = -1;
+        return;
+    }
+    double *e = s_e[wave], *cdf = s_c[wave];
+    const int S = st.S;
+    const TreeView t = tree_view(st, g, st.cur[g]);
+    const int base = t.child[0];
+    const int K = base >= 0 ? meta_k(t.meta[0]) : 0;
+    const int ply = st.ply[g];
+    int child_idx = -1;
+
+    if ((flags & (ADV_SAMPLE | ADV_RECORD)) && K > 0) {
+        // pi = softmax(1.0/temp * log(visits + 1e-10))   (mcts_alphaZero.py:16-19,179)
+        double mx = -HUGE_VAL;
+        for (int i = lane; i < K; i += WAVE) {
+            const double x = (1.0 / temp) * log((double)t.N[base + i] + 1e-10);
+            e[i] = x;
+            mx = fmax(mx, x);
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) mx = fmax(mx, __shfl_xor(mx, off));
+        for (int i = lane; i < K; i += WAVE) e[i] = exp(e[i] - mx);
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        double tot = 0.0;
+        if (lane == 0) tot = np_sum(e, K);
+        tot = __shfl(tot, 0);
+        for (int i = lane; i < K; i += WAVE) e[i] = e[i] / tot;
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        if (flags & ADV_SAMPLE) {
+            // np.random.choice(acts, p = 0.75*probs + 0.25*dirichlet): cdf = cumsum(p);
+            // cdf /= cdf[-1]; index = searchsorted(cdf, u, side='right')
+            if (lane == 0) {
+                double run = 0.0;
+                for (int i = 0; i < K; i++) {
+                    run += 0.75 * e[i] + 0.25 * noise[(size_t)g * S + i];
+                    cdf[i] = run;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            const double last = cdf[K - 1], u = u01[g];
+            int cnt = 0;
+            for (int i = lane; i < K; i += WAVE) cnt += (cdf[i] / last <= u) ? 1 : 0;
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) cnt += __shfl_xor(cnt, off);
+            child_idx = min(cnt, K - 1);
+            move = meta_act(t.meta[base + child_idx]);
+        }
+    }
+    if (!(flags & ADV_SAMPLE)) {
+        move = given[g];
+        for (int i0 = 0; i0 < K; i0 += WAVE) {
+            const int i = i0 + lane;
+            const bool hit = i < K && meta_act(t.meta[base + i]) == move;
+            const u64 m = __ballot(hit);
+            if (m) { child_idx = i0 + __ffsll((long long)m) - 1; break; }
+        }
+    }
+    if (moves_out && lane == 0) moves_out[g] = move;
+
+    // training sample: state before the move, pi by cell (game.py:381-383)
+    if (flags & ADV_RECORD) {
+        const int sc = st.s_count[g];
+        if (sc < S) {
+            double *pi = st.s_pi + ((size_t)g * S + sc) * S;
+            for (int i = lane; i < S; i += WAVE) pi[i] = 0.0;
+            wg_fence();
+            for (int i = lane; i < K; i += WAVE) pi[meta_act(t.meta[base + i])] = e[i];
+            if (lane < 2 * MAXW) st.s_bb[((size_t)g * S + sc) * 2 * MAXW + lane] = st.bb[(size_t)g * 2 * MAXW + lane];
+            if (lane == 0) { st.s_last[(size_t)g * S + sc] = st.last_move[g]; st.s_ply[(size_t)g * S + sc] = ply; st.s_count[g] = sc + 1; }
+        }
+    }
+    if (pi_out) {
+        for (int i = lane; i < S; i += WAVE) pi_out[(size_t)g * S + i] = 0.0;
+        wg_fence();
+        if (flags & (ADV_SAMPLE | ADV_RECORD))
+            for (int i = lane; i < K; i += WAVE) pi_out[(size_t)g * S + meta_act(t.meta[base + i])] = e[i];
+    }
+
+    bool ended = false;
+    if (flags & ADV_BOARD) {
+        // Board.do_move (game.py:119-127) then game_end (game.py:162-169)
+        const int mover = player_at(st.first_player[g], ply);
+        if (lane < 2 * MAXW) ((u64 *)s_bbw[wave])[lane] = st.bb[(size_t)g * 2 * MAXW + lane];
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        const bool occupied = bb_has(s_bbw[wave][0], move) || bb_has(s_bbw[wave][1], move);
+        if (occupied || move < 0 || move >= S) {
+            if (lane == 0) st.err[g] |= 2;
+            return;
+        }
+        if (lane == 0) s_bbw[wave][mover - 1][move >> 6] |= 1ULL << (move & 63);
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        const int term = wave_game_end(s_bbw[wave], st.N, S, st.n_in_row, ply + 1, lane);
+        if (lane < 2 * MAXW) st.bb[(size_t)g * 2 * MAXW + lane] = ((u64 *)s_bbw[wave])[lane];
+        if (lane == 0) {
+            st.ply[g] = ply + 1;
+            st.last_move[g] = move;
+            if (term) { st.status[g] = 1; st.winner[g] = (signed char)(term == 3 ? -1 : term); }
+        }
+        ended = term != 0;
+    }
+    if (flags & ADV_REROOT) {
+        if (ended || child_idx < 0) {
+            if (lane == 0) fresh_root(st, g, st.cur[g]);      // reset_player / unknown move
+        } else {
+            wave_reroot(st, g, base + child_idx, lane);
+        }
+    }
+}
+
+// MCTS.update_with_move alone (board untouched): moves[g] >= 0 re-root, -1 fresh, -2 skip.
+__global__ __launch_bounds__(256) void reroot_kernel(DevState st, const int *moves)
+{
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int g = blockIdx.x * 4 + wave;
+    if (g >= st.B) return;
+    const int move = moves[g];
+    if (move == -2) return;
+    const TreeView t = tree_view(st, g, st.cur[g]);
+    const int base = t.child[0];
+    const int K = base >= 0 ? meta_k(t.meta[0]) : 0;
+    int child_idx = -1;
+    if (move >= 0)
+        for (int i0 = 0; i0 < K; i0 += WAVE) {
+            const int i = i0 + lane;
+            const bool hit = i < K && meta_act(t.meta[base + i]) == move;
+            const u64 m = __ballot(hit);
+            if (m) { child_idx = i0 + __ffsll((long long)m) - 1; break; }
+        }
+    if (child_idx < 0) { if (lane == 0) fresh_root(st, g, st.cur[g]); }
+    else wave_reroot(st, g, base + child_idx, lane);
+}
+
+// ---------------------------------------------------------------- reset / set position
+__global__ void reset_kernel(DevState st, const unsigned char *mask, const long long *ids)
+{
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= st.B || (mask && !mask[g])) return;
+    for (int i = 0; i < 2 * MAXW; i++) st.bb[(size_t)g * 2 * MAXW + i] = 0;
+    st.ply[g] = 0; st.last_move[g] = -1; st.first_player[g] = 1;
+    st.status[g] = 0; st.winner[g] = -1; st.err[g] = 0;
+    st.s_count[g] = 0; st.drained[g] = 0;
+    st.game_id[g] = ids ? ids[g] : (long long)g;
+    fresh_root(st, g, 0);
+}
+
+// ---------------------------------------------------------------- read-outs
+// Root children statistics by cell (mcts_alphaZero.py:166-168).
+__global__ void root_stats_kernel(DevState st, int *visits, double *q, double *prior, int *root_n)
+{
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int g = blockIdx.x * 4 + wave;
+    if (g >= st.B) return;
+    const TreeView t = tree_view(st, g, st.cur[g]);
+    for (int i = lane; i < st.S; i += WAVE) {
+        if (visits) visits[(size_t)g * st.S + i] = 0;
+        if (q) q[(size_t)g * st.S + i] = 0.0;
+        if (prior) prior[(size_t)g * st.S + i] = 0.0;
+    }
+    wg_fence();
+    const int base = t.child[0];
+    const int K = base >= 0 ? meta_k(t.meta[0]) : 0;
+    for (int i = lane; i < K; i += WAVE) {
+        const int a = meta_act(t.meta[base + i]);
+        if (visits) visits[(size_t)g * st.S + a] = t.N[base + i];
+        if (q) q[(size_t)g * st.S + a] = t.Q[base + i];
+        if (prior) prior[(size_t)g * st.S + a] = (double)t.P[base + i];
+    }
+    if (root_n && lane == 0) root_n[g] = t.N[0];
+}
+
+// Board.current_state (game.py:92-116) of every slot, float32 [B][4][N][N].
+__global__ void states_kernel(DevState st, float *out)
+{
+    const int g = blockIdx.x;
+    const int S = st.S, N = st.N;
+    const u64(*bb)[MAXW] = reinterpret_cast<const u64(*)[MAXW]>(st.bb + (size_t)g * 2 * MAXW);
+    const int ply = st.ply[g], last = st.last_move[g];
+    const int cur = player_at(st.first_player[g], ply);
+    for (int idx = threadIdx.x; idx < 4 * S; idx += blockDim.x) {
+        const int pl = idx / S, rem = idx - pl * S;
+        out[(size_t)g * 4 * S + idx] = plane_value(bb, N, ply, last, cur, pl, rem / N, rem % N);
+    }
+}
+
+// (state, pi, z) tuples of finished games (game.py:393-416).  map_g/map_t give slot and
+// sample index of output row i.
+__global__ void drain_kernel(DevState st, int n, const int *map_g, const int *map_t, float *states,
+                             double *pi, float *z, long long *gid, int *ply_out)
+{
+    const int i = blockIdx.x;
+    if (i >= n) return;
+    const int g = map_g[i], t = map_t[i];
+    const int S = st.S, N = st.N;
+    const u64(*bb)[MAXW] = reinterpret_cast<const u64(*)[MAXW]>(st.s_bb + ((size_t)g * S + t) * 2 * MAXW);
+    const int ply = st.s_ply[(size_t)g * S + t], last = st.s_last[(size_t)g * S + t];
+    const int cur = player_at(st.first_player[g], ply);
+    if (states)
+        for (int idx = threadIdx.x; idx < 4 * S; idx += blockDim.x) {
+            const int pl = idx / S, rem = idx - pl * S;
+            states[(size_t)i * 4 * S + idx] = plane_value(bb, N, ply, last, cur, pl, rem / N, rem % N);
+        }
+    if (pi)
+        for (int idx = threadIdx.x; idx < S; idx += blockDim.x)
+            pi[(size_t)i * S + idx] = st.s_pi[((size_t)g * S + t) * S + idx];
+    if (threadIdx.x == 0) {
+        const int w = st.winner[g];
+        if (z) z[i] = (w == -1) ? 0.0f : (w == cur ? 1.0f : -1.0f);
+        if (gid) gid[i] = st.game_id[g];
+        if (ply_out) ply_out[i] = ply;
+    }
+}
+
+// Stateless Board.do_move + game_end + current_state for n boards, one per wave.
+__global__ __launch_bounds__(256) void board_step_kernel(int N, int nrow, int n, u64 *stones, int *ply,
+                                                         int *last, const int *moves, const int *player,
+                                                         unsigned char *ended, signed char *winner,
+                                                         float *planes, int *bad)
+{
+    __shared__ u64 s_bbw[4][2][MAXW];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + wave;
+    if (b >= n) return;
+    const int S = N * N;
+    if (lane < 2 * MAXW) ((u64 *)s_bbw[wave])[lane] = stones[(size_t)b * 2 * MAXW + lane];
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    const int mv = moves[b], pl = player[b];
+    if (mv < 0 || mv >= S || bb_has(s_bbw[wave][0], mv) || bb_has(s_bbw[wave][1], mv) || pl < 1 || pl > 2) {
+        if (lane == 0) atomicOr(bad, 1);
+        return;
+    }
+    if (lane == 0) s_bbw[wave][pl - 1][mv >> 6] |= 1ULL << (mv & 63);
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    const int np = ply[b] + 1;
+    const int term = wave_game_end(s_bbw[wave], N, S, nrow, np, lane);
+    if (lane < 2 * MAXW) stones[(size_t)b * 2 * MAXW + lane] = ((u64 *)s_bbw[wave])[lane];
+    if (lane == 0) {
+        ply[b] = np; last[b] = mv;
+        ended[b] = term != 0;
+        winner[b] = (signed char)((term == 0 || term == 3) ? -1 : term);
+    }
+    if (planes) {
+        const int cur = 3 - pl;
+        for (int idx = lane; idx < 4 * S; idx += WAVE) {
+            const int p = idx / S, rem = idx - p * S;
+            planes[(size_t)b * 4 * S + idx] = plane_value(s_bbw[wave], N, np, mv, cur, p, rem / N, rem % N);
+        }
+    }
+}
+
+}  // namespace azg

@@ -1,0 +1,269 @@
+// Wave-level (64 lanes, one game per wave) board and PUCT tree primitives.
+//
+// Reference semantics restated here (files relative to the reference tree):
+//   Board.do_move / has_a_winner / game_end / current_state   game.py:92-169
+//   TreeNode.select / get_value / expand / update_recursive   mcts_alphaZero.py:38-83
+//   MCTS._playout                                             mcts_alphaZero.py:113-148
+// All tree arithmetic is IEEE double in the reference's operation order; this file
+// must be compiled with -ffp-contract=off.
+#pragma once
+#include "azg_device.hpp"
+
+namespace azg {
+
+typedef unsigned long long u64;
+
+// ---------------------------------------------------------------- small helpers
+__device__ inline u64 mix64(u64 z)
+{
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+
+// bit c of a MAXW-word set kept in LDS or global memory
+__device__ inline bool bb_has(const u64 *set, int c) { return (set[c >> 6] >> (c & 63)) & 1ULL; }
+
+// Working copy of one game during a search (lives in LDS).
+struct GameLds {
+    u64 root_bb[2][MAXW];
+    u64 leaf_bb[2][MAXW];
+    int path[MAXS + 1];        // edge indices root .. leaf
+    int depth;                 // entries in path
+    int root_ply, root_last, first_player;
+    int leaf_ply, leaf_last;
+    int live;
+    int term;                  // leaf ended: 0 no, 1/2 winner, 3 tie
+    int need_eval;             // leaf needs priors/value from the provider
+    int gid;                   // slot index
+};
+
+struct TreeView {              // live arena of one game
+    float *P; int *N; double *Q; int *child; unsigned *meta;
+};
+
+__device__ inline TreeView tree_view(const DevState &st, int g, int arena)
+{
+    size_t off = ((size_t)g * 2 + (size_t)arena) * (size_t)st.cap;
+    TreeView t;
+    t.P = st.eP + off; t.N = st.eN + off; t.Q = st.eQ + off;
+    t.child = st.eChild + off; t.meta = st.eMeta + off;
+    return t;
+}
+
+// Lanes of one wave exchange data through LDS (one lane writes, others read).  The
+// hardware executes a wave's LDS instructions in order, but the compiler sees 64
+// independent threads, so every such hand-over needs a wavefront-scope fence to keep
+// the reads behind the join of the writing branch.
+__device__ inline void wave_sync() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); }
+
+// Outcome of a descent, identical in every lane.
+struct Descent {
+    int leaf;        // edge index of the leaf
+    int depth;       // entries in GameLds::path (root .. leaf)
+    int ply;         // stones on the leaf board
+    int last;        // last move on the leaf board
+};
+
+// side to move (1 or 2) at a given ply
+__device__ inline int player_at(int first_player, int ply)
+{
+    return (ply & 1) ? (3 - first_player) : first_player;
+}
+
+// ---------------------------------------------------------------- game_end
+// game.py:129-169 on a stone-set pair.  Every lane owns cells lane, lane+64, ...;
+// a cell "wins" when it anchors an n-long ray of its owner's stones in one of the
+// four reference directions.  The reference scans anchors in ascending order and
+// reports the owner of the first hit.  Returns 0 (not ended), 1 / 2 (winner) or
+// 3 (tie); wave-uniform.
+__device__ inline int wave_game_end(const u64 (*bb)[MAXW], int N, int S, int nrow, int nstones,
+                                    int lane)
+{
+    if (nstones >= nrow + 2) {                                   // game.py:136-137
+        for (int c0 = 0; c0 < S; c0 += WAVE) {
+            const int c = c0 + lane;
+            int p = 0;
+            bool hit = false;
+            if (c < S) {
+                p = bb_has(bb[0], c) ? 1 : (bb_has(bb[1], c) ? 2 : 0);
+                if (p) {
+                    const u64 *mine = bb[p - 1];
+                    const int h = c / N, w = c - h * N;
+                    const bool wr = (w <= N - nrow), hr = (h <= N - nrow), wl = (w >= nrow - 1);
+                    bool a = wr, b = hr, d = wr && hr, e = wl && hr;
+                    for (int j = 1; j < nrow; j++) {
+                        if (a) a = bb_has(mine, c + j);
+                        if (b) b = bb_has(mine, c + j * N);
+                        if (d) d = bb_has(mine, c + j * (N + 1));
+                        if (e) e = bb_has(mine, c + j * (N - 1));
+                    }
+                    hit = a || b || d || e;
+                }
+            }
+            const u64 m = __ballot(hit);
+            if (m) {
+                const int src = __ffsll((long long)m) - 1;
+                return __shfl(p, src);
+            }
+        }
+    }
+    return nstones == S ? 3 : 0;                                 // game.py:167-168
+}
+
+// ---------------------------------------------------------------- select
+// Descend from the root to a leaf (mcts_alphaZero.py:122-129).  Lanes hold one child
+// each (four at most on 16x16); the argmax keeps the first maximum in ascending child
+// order, which is the order `max()` meets them in the reference.
+__device__ inline Descent wave_select(const DevState &st, const TreeView &t, GameLds *gl, int lane)
+{
+    // leaf board starts as a copy of the root board (copy.deepcopy, :162)
+    if (lane < 2 * MAXW) ((u64 *)gl->leaf_bb)[lane] = ((u64 *)gl->root_bb)[lane];
+    wave_sync();
+    int e = 0;                       // root edge
+    int depth = 1;
+    int ply = gl->root_ply, last = gl->root_last;
+    int child = t.child[0];
+    int K = meta_k(t.meta[0]);
+    int Np = t.N[0];
+    if (lane == 0) gl->path[0] = 0;
+    while (child >= 0) {
+        const double sq = sqrt((double)Np);                      // np.sqrt(parent._n_visits)
+        double best = -HUGE_VAL;
+        int bidx = 0x7fffffff, bchild = -1, bn = 0;
+        unsigned bmeta = 0;
+        for (int i = lane; i < K; i += WAVE) {
+            const int ei = child + i;
+            const double q = t.Q[ei];
+            const float p = t.P[ei];
+            const int n = t.N[ei];
+            const int ch = t.child[ei];
+            const unsigned mt = t.meta[ei];
+            // get_value (:82-83): c_puct * P * sqrt(Np) / (1 + n), left to right, then Q + u
+            const double u = ((st.c_puct * (double)p) * sq) / (double)(1 + n);
+            const double s = q + u;
+            if (s > best) { best = s; bidx = i; bchild = ch; bn = n; bmeta = mt; }
+        }
+        double rs = best;
+        int ri = bidx;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const double os = __shfl_xor(rs, off);
+            const int oi = __shfl_xor(ri, off);
+            if (os > rs || (os == rs && oi < ri)) { rs = os; ri = oi; }
+        }
+        const int src = ri & 63;
+        e = child + ri;
+        child = __shfl(bchild, src);
+        Np = __shfl(bn, src);
+        const unsigned mt = __shfl(bmeta, src);
+        K = meta_k(mt);
+        const int act = meta_act(mt);
+        // Board.do_move (game.py:119-127) on the leaf copy
+        if (lane == 0) {
+            const int mover = player_at(gl->first_player, ply);
+            gl->leaf_bb[mover - 1][act >> 6] |= 1ULL << (act & 63);
+            gl->path[depth] = e;
+        }
+        depth++;
+        ply++;
+        last = act;
+    }
+    if (lane == 0) { gl->depth = depth; gl->leaf_ply = ply; gl->leaf_last = last; }
+    wave_sync();
+    Descent d;
+    d.leaf = e; d.depth = depth; d.ply = ply; d.last = last;
+    return d;
+}
+
+// ---------------------------------------------------------------- expand
+// TreeNode.expand (:38-45): one child per empty cell in ascending order, prior taken
+// from the provider's per-cell output without renormalisation.  `prior_of(cell)`
+// returns the float32 prior.  Returns false when the arena is full.
+template <typename PriorFn>
+__device__ inline bool wave_expand(const DevState &st, const TreeView &t, const GameLds *gl,
+                                   const Descent &d, int g, int lane, PriorFn prior_of)
+{
+    const int leaf = d.leaf;
+    const int K = st.S - d.ply;
+    const int base = st.used[g];
+    if (base + K > st.cap) {
+        if (lane == 0) st.err[g] |= 1;
+        return false;
+    }
+    int before = 0;
+    for (int c0 = 0; c0 < st.S; c0 += WAVE) {
+        const int c = c0 + lane;
+        const bool empty = (c < st.S) && !bb_has(gl->leaf_bb[0], c) && !bb_has(gl->leaf_bb[1], c);
+        const u64 m = __ballot(empty);
+        if (empty) {
+            const int rank = before + __popcll(m & ((1ULL << lane) - 1ULL));
+            const int ei = base + rank;
+            t.P[ei] = prior_of(c);
+            t.N[ei] = 0;
+            t.Q[ei] = 0.0;
+            t.child[ei] = -1;
+            t.meta[ei] = meta_pack(c, 0);
+        }
+        before += __popcll(m);
+    }
+    if (lane == 0) {
+        t.child[leaf] = base;
+        t.meta[leaf] = meta_pack(meta_act(t.meta[leaf]), K);
+        st.used[g] = base + K;
+    }
+    return true;
+}
+
+// ---------------------------------------------------------------- backup
+// update_recursive(-leaf_value) (:57-73): N += 1; Q += 1.0*(x - Q)/N from the leaf up
+// to and including the root, x changing sign at every step.
+__device__ inline void wave_backup(const TreeView &t, const GameLds *gl, int depth, double leaf_value,
+                                   int lane)
+{
+    const int d = depth;
+    for (int j = lane; j < d; j += WAVE) {
+        const int e = gl->path[j];
+        const double x = ((d - 1 - j) & 1) ? leaf_value : -leaf_value;
+        const int n = t.N[e] + 1;
+        const double q = t.Q[e];
+        t.N[e] = n;
+        t.Q[e] = q + (1.0 * (x - q)) / (double)n;
+    }
+}
+
+// ---------------------------------------------------------------- synthetic providers
+__device__ inline u64 state_key(const u64 (*bb)[MAXW], int NW, int current_player)
+{
+    u64 k = 0x9E3779B97F4A7C15ULL ^ (u64)current_player;
+    for (int c = 0; c < 2; c++)
+        for (int w = 0; w < NW; w++) k = mix64(k ^ bb[c][w]);
+    return k;
+}
+
+__device__ inline float hash_prior(u64 key, int a)
+{
+    const u64 r = (mix64(key + 0x9E3779B97F4A7C15ULL * (u64)(a + 1)) >> 32) & 0xFFFULL;
+    return (float)(r + 1) / 131072.0f;
+}
+
+__device__ inline double hash_value(u64 key)
+{
+    const u64 rv = (mix64(key ^ 0xD1B54A32D192ED03ULL) >> 32) & 0xFFFULL;
+    return ((double)rv - 2048.0) / 2048.0;
+}
+
+// ---------------------------------------------------------------- feature planes
+// Board.current_state (game.py:92-116) of one position: value of plane `pl` at plane
+// coordinates (row, col); the cell shown at plane row r is board row N-1-r.
+__device__ inline float plane_value(const u64 (*bb)[MAXW], int N, int ply, int last, int cur_player,
+                                    int pl, int row, int col)
+{
+    const int cell = (N - 1 - row) * N + col;
+    if (pl == 0) return bb_has(bb[cur_player - 1], cell) ? 1.0f : 0.0f;
+    if (pl == 1) return bb_has(bb[2 - cur_player], cell) ? 1.0f : 0.0f;
+    if (pl == 2) return (ply > 0 && cell == last) ? 1.0f : 0.0f;
+    return (ply & 1) ? 0.0f : 1.0f;
+}
+
+}  // namespace azg

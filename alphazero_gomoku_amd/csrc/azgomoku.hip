@@ -1,0 +1,702 @@
+// libazgomoku.so -- C ABI (include/azgomoku.h) over the HIP kernels in azg_kernels.hpp.
+// Host side: memory, launches, the numpy-legacy noise stream, repacking of weights.
+#include "../../include/azgomoku.h"
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <cstdlib>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "azg_kernels.hpp"
+#include "np_legacy_rng.hpp"
+
+using namespace azg;
+
+static thread_local std::string g_create_error;
+
+struct azg_handle {
+    azg_config cfg{};
+    DevState st{};
+    hipStream_t stream = nullptr;
+    std::string err;
+    std::vector<void *> allocs;
+    bool have_weights = false;
+    float *d_weights = nullptr;
+    // host mirrors, refreshed after every state-changing call
+    std::vector<int> h_ply, h_scount, h_err;
+    std::vector<signed char> h_status, h_winner;
+    std::vector<unsigned char> h_drained;
+    std::vector<NpLegacyRng> rng;
+    // pinned staging
+    double *h_noise = nullptr, *h_u = nullptr;
+    int *h_moves = nullptr;
+    signed char *h_sc = nullptr;     // status | winner
+    int *h_ints = nullptr;           // ply | s_count | err
+    double *d_noise = nullptr, *d_u = nullptr, *d_pi = nullptr;
+    int *d_moves = nullptr, *d_given = nullptr;
+    // grow-on-demand device scratch
+    void *scratch[8] = {nullptr};
+    size_t scratch_sz[8] = {0};
+    // profiling
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+    size_t ev_pending = 0;
+    long long prof_launches = 0;
+    double prof_ms = 0.0;
+};
+
+static int fail(azg_handle *h, int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (h) h->err = buf;
+    else g_create_error = buf;
+    return code;
+}
+
+#define HIPCHK(h, call)                                                                          \
+    do {                                                                                         \
+        hipError_t e_ = (call);                                                                  \
+        if (e_ != hipSuccess)                                                                    \
+            return fail(h, AZG_EHIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+template <typename T>
+static int dev_alloc(azg_handle *h, T **p, size_t count, bool zero = true)
+{
+    void *q = nullptr;
+    HIPCHK(h, hipMalloc(&q, std::max<size_t>(count, 1) * sizeof(T)));
+    h->allocs.push_back(q);
+    if (zero) HIPCHK(h, hipMemsetAsync(q, 0, std::max<size_t>(count, 1) * sizeof(T), h->stream));
+    *p = reinterpret_cast<T *>(q);
+    return AZG_OK;
+}
+
+static int scratch_get(azg_handle *h, int slot, size_t bytes, void **out)
+{
+    if (h->scratch_sz[slot] < bytes) {
+        if (h->scratch[slot]) HIPCHK(h, hipFree(h->scratch[slot]));
+        h->scratch[slot] = nullptr;
+        h->scratch_sz[slot] = 0;
+        size_t want = std::max<size_t>(bytes, 256);
+        HIPCHK(h, hipMalloc(&h->scratch[slot], want));
+        h->scratch_sz[slot] = want;
+    }
+    *out = h->scratch[slot];
+    return AZG_OK;
+}
+
+// ---------------------------------------------------------------- kernel dispatch
+struct SearchLaunch {
+    void (*fn)(DevState);
+    int T;
+    size_t lds;
+};
+
+template <int N, int T>
+static SearchLaunch net_launch()
+{
+    using G = CnnGeom<N, T>;
+    return {search_kernel<N, T, 0>, T, (size_t)G::END * 4 + T * sizeof(GameLds)};
+}
+
+static bool pick_search(int N, int mode, SearchLaunch *out)
+{
+    if (mode == AZG_PRIOR_UNIFORM32) { *out = {search_kernel<0, 4, 1>, 4, 4 * sizeof(GameLds)}; return true; }
+    if (mode == AZG_PRIOR_HASH) { *out = {search_kernel<0, 4, 2>, 4, 4 * sizeof(GameLds)}; return true; }
+    switch (N) {
+    case 6: *out = net_launch<6, 2>(); return true;
+    case 8: *out = net_launch<8, 2>(); return true;
+    case 15: *out = net_launch<15, 1>(); return true;
+    default: return false;
+    }
+}
+
+struct EvalLaunch {
+    void (*fn)(NetWeights, const float *, int, float *, float *);
+    int T;
+    size_t lds;
+};
+
+template <int N, int T>
+static EvalLaunch eval_launch()
+{
+    using G = CnnGeom<N, T>;
+    return {eval_kernel<N, T>, T, (size_t)G::END * 4};
+}
+
+static bool pick_eval(int N, EvalLaunch *out)
+{
+    switch (N) {
+    case 6: *out = eval_launch<6, 2>(); return true;
+    case 8: *out = eval_launch<8, 2>(); return true;
+    case 15: *out = eval_launch<15, 1>(); return true;
+    default: return false;
+    }
+}
+
+// ---------------------------------------------------------------- mirrors / profiling
+static int harvest_events(azg_handle *h)
+{
+    for (size_t i = 0; i < h->ev_pending; i++) {
+        float ms = 0.f;
+        HIPCHK(h, hipEventElapsedTime(&ms, h->ev_pool[i].first, h->ev_pool[i].second));
+        h->prof_ms += ms;
+        h->prof_launches++;
+    }
+    h->ev_pending = 0;
+    return AZG_OK;
+}
+
+static int refresh_mirrors(azg_handle *h)
+{
+    const int B = h->cfg.n_games;
+    HIPCHK(h, hipMemcpyAsync(h->h_sc, h->st.status, B, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->h_sc + B, h->st.winner, B, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->h_ints, h->st.ply, B * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->h_ints + B, h->st.s_count, B * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->h_ints + 2 * B, h->st.err, B * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    for (int g = 0; g < B; g++) {
+        h->h_status[g] = h->h_sc[g];
+        h->h_winner[g] = h->h_sc[B + g];
+        h->h_ply[g] = h->h_ints[g];
+        h->h_scount[g] = h->h_ints[B + g];
+        h->h_err[g] = h->h_ints[2 * B + g];
+    }
+    int rc = harvest_events(h);
+    if (rc) return rc;
+    for (int g = 0; g < B; g++) {
+        if (h->h_err[g] & 1) return fail(h, AZG_EARENA, "slot %d: search tree outgrew its arena (arena_nodes=%d)", g, h->cfg.arena_nodes);
+        if (h->h_err[g] & 2) return fail(h, AZG_EMOVE, "slot %d: illegal move", g);
+    }
+    return AZG_OK;
+}
+
+// ---------------------------------------------------------------- create / destroy
+extern "C" const char *azg_last_error(const azg_handle *h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+extern "C" void azg_destroy(azg_handle *h)
+{
+    if (!h) return;
+    (void)hipSetDevice(h->cfg.device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    for (void *p : h->allocs) (void)hipFree(p);
+    for (void *p : h->scratch) if (p) (void)hipFree(p);
+    if (h->d_weights) (void)hipFree(h->d_weights);
+    if (h->h_noise) (void)hipHostFree(h->h_noise);
+    if (h->h_u) (void)hipHostFree(h->h_u);
+    if (h->h_moves) (void)hipHostFree(h->h_moves);
+    if (h->h_sc) (void)hipHostFree(h->h_sc);
+    if (h->h_ints) (void)hipHostFree(h->h_ints);
+    for (auto &e : h->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+static int create_impl(azg_handle *h)
+{
+    const azg_config &c = h->cfg;
+    const int N = c.board_n, S = N * N, B = c.n_games;
+    HIPCHK(h, hipSetDevice(c.device));
+    HIPCHK(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    DevState &st = h->st;
+    st.N = N; st.S = S; st.NW = (S + 63) / 64; st.n_in_row = c.n_in_row; st.B = B;
+    st.prior_mode = c.prior_mode; st.n_playout = c.n_playout; st.c_puct = c.c_puct;
+    st.cap = 1 + h->cfg.arena_nodes * S;
+    const size_t E = (size_t)B * 2 * st.cap;
+    int rc;
+    if ((rc = dev_alloc(h, &st.bb, (size_t)B * 2 * MAXW))) return rc;
+    if ((rc = dev_alloc(h, &st.ply, B))) return rc;
+    if ((rc = dev_alloc(h, &st.last_move, B))) return rc;
+    if ((rc = dev_alloc(h, &st.first_player, B))) return rc;
+    if ((rc = dev_alloc(h, &st.status, B))) return rc;
+    if ((rc = dev_alloc(h, &st.winner, B))) return rc;
+    if ((rc = dev_alloc(h, &st.err, B))) return rc;
+    if ((rc = dev_alloc(h, &st.eP, E, false))) return rc;
+    if ((rc = dev_alloc(h, &st.eN, E, false))) return rc;
+    if ((rc = dev_alloc(h, &st.eQ, E, false))) return rc;
+    if ((rc = dev_alloc(h, &st.eChild, E, false))) return rc;
+    if ((rc = dev_alloc(h, &st.eMeta, E, false))) return rc;
+    if ((rc = dev_alloc(h, &st.used, B))) return rc;
+    if ((rc = dev_alloc(h, &st.cur, B))) return rc;
+    if ((rc = dev_alloc(h, &st.evals, B))) return rc;
+    if ((rc = dev_alloc(h, &st.s_bb, (size_t)B * S * 2 * MAXW, false))) return rc;
+    if ((rc = dev_alloc(h, &st.s_last, (size_t)B * S, false))) return rc;
+    if ((rc = dev_alloc(h, &st.s_ply, (size_t)B * S, false))) return rc;
+    if ((rc = dev_alloc(h, &st.s_pi, (size_t)B * S * S, false))) return rc;
+    if ((rc = dev_alloc(h, &st.s_count, B))) return rc;
+    if ((rc = dev_alloc(h, &st.game_id, B))) return rc;
+    if ((rc = dev_alloc(h, &st.drained, B))) return rc;
+    if ((rc = dev_alloc(h, &h->d_noise, (size_t)B * S))) return rc;
+    if ((rc = dev_alloc(h, &h->d_u, B))) return rc;
+    if ((rc = dev_alloc(h, &h->d_pi, (size_t)B * S))) return rc;
+    if ((rc = dev_alloc(h, &h->d_moves, B))) return rc;
+    if ((rc = dev_alloc(h, &h->d_given, B))) return rc;
+    HIPCHK(h, hipHostMalloc((void **)&h->h_noise, (size_t)B * S * sizeof(double)));
+    HIPCHK(h, hipHostMalloc((void **)&h->h_u, (size_t)B * sizeof(double)));
+    HIPCHK(h, hipHostMalloc((void **)&h->h_moves, (size_t)B * sizeof(int)));
+    HIPCHK(h, hipHostMalloc((void **)&h->h_sc, (size_t)B * 2));
+    HIPCHK(h, hipHostMalloc((void **)&h->h_ints, (size_t)B * 3 * sizeof(int)));
+    h->h_ply.assign(B, 0); h->h_scount.assign(B, 0); h->h_err.assign(B, 0);
+    h->h_status.assign(B, 2); h->h_winner.assign(B, -1); h->h_drained.assign(B, 1);
+    h->rng.resize(B);
+    // every slot starts idle (status 2) until azg_reset_games
+    HIPCHK(h, hipMemsetAsync(st.status, 2, B, h->stream));
+    HIPCHK(h, hipMemsetAsync(st.drained, 1, B, h->stream));
+    // opt in to the large dynamic LDS of the CNN kernels
+    SearchLaunch sl;
+    if (pick_search(N, c.prior_mode, &sl))
+        HIPCHK(h, hipFuncSetAttribute((const void *)sl.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sl.lds));
+    EvalLaunch el;
+    if (pick_eval(N, &el))
+        HIPCHK(h, hipFuncSetAttribute((const void *)el.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)el.lds));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return AZG_OK;
+}
+
+extern "C" int azg_create(const azg_config *cfg, azg_handle **out)
+{
+    if (!cfg || !out) return fail(nullptr, AZG_EINVAL, "null argument");
+    *out = nullptr;
+    if (cfg->board_n < 3 || cfg->board_n > 16) return fail(nullptr, AZG_EINVAL, "board_n must be in [3,16], got %d", cfg->board_n);
+    if (cfg->n_in_row < 1 || cfg->n_in_row > cfg->board_n)
+        return fail(nullptr, AZG_EINVAL, "board width and height can not be less than n_in_row (%d)", cfg->n_in_row);
+    if (cfg->n_games < 1) return fail(nullptr, AZG_EINVAL, "n_games must be positive");
+    if (cfg->n_playout < 1) return fail(nullptr, AZG_EINVAL, "n_playout must be positive");
+    if (cfg->prior_mode < 0 || cfg->prior_mode > 2) return fail(nullptr, AZG_EINVAL, "bad prior_mode %d", cfg->prior_mode);
+    SearchLaunch sl;
+    if (!pick_search(cfg->board_n, cfg->prior_mode, &sl))
+        return fail(nullptr, AZG_EINVAL, "no CNN search kernel is built for board_n=%d (built: 6, 8, 15)", cfg->board_n);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(nullptr, AZG_EHIP, "no HIP device available");
+    if (cfg->device < 0 || cfg->device >= ndev) return fail(nullptr, AZG_EINVAL, "device %d out of range (%d devices)", cfg->device, ndev);
+    azg_handle *h = new azg_handle();
+    h->cfg = *cfg;
+    if (h->cfg.arena_nodes <= 0) h->cfg.arena_nodes = 4 * cfg->n_playout + 64;
+    int rc = create_impl(h);
+    if (rc != AZG_OK) {
+        g_create_error = h->err;
+        azg_destroy(h);
+        return rc;
+    }
+    *out = h;
+    return AZG_OK;
+}
+
+extern "C" void *azg_stream(azg_handle *h) { return h ? (void *)h->stream : nullptr; }
+
+// ---------------------------------------------------------------- weights
+static void pack_conv(const float *w, int cin, int cout, float *out)
+{
+    const int KS = (cin / 2) * 9;
+    for (int cot = 0; cot < cout / 32; cot++)
+        for (int ks = 0; ks < KS; ks++)
+            for (int lane = 0; lane < 64; lane++) {
+                const int co = cot * 32 + (lane & 31), ci = 2 * (ks / 9) + (lane >> 5), tap = ks % 9;
+                out[((size_t)cot * KS + ks) * 64 + lane] = w[((size_t)co * cin + ci) * 9 + tap];
+            }
+}
+
+extern "C" int azg_set_weights(azg_handle *h, const float *const ptrs[16], int layout)
+{
+    if (!h || !ptrs) return fail(h, AZG_EINVAL, "null argument");
+    if (layout != AZG_LAYOUT_TORCH && layout != AZG_LAYOUT_THEANO) return fail(h, AZG_EINVAL, "bad layout %d", layout);
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    const int S = h->st.S;
+    const size_t sizes[16] = {32 * 4 * 9, 32, 64 * 32 * 9, 64, 128 * 64 * 9, 128, 4 * 128, 4,
+                              (size_t)S * 4 * S, (size_t)S, 2 * 128, 2, (size_t)64 * 2 * S, 64, 64, 1};
+    std::vector<std::vector<float>> t(16);
+    for (int i = 0; i < 16; i++) {
+        if (!ptrs[i]) return fail(h, AZG_EINVAL, "weight tensor %d is null", i);
+        t[i].resize(sizes[i]);
+        HIPCHK(h, hipMemcpy(t[i].data(), ptrs[i], sizes[i] * sizeof(float), hipMemcpyDefault));
+    }
+    if (layout == AZG_LAYOUT_THEANO) {
+        // conv kernels are stored for true convolution (rotated 180 degrees) and FC
+        // matrices as (in, out): policy_value_net_numpy.py:27-29,43-45
+        for (int i : {0, 2, 4}) {
+            const size_t n = sizes[i] / 9;
+            for (size_t k = 0; k < n; k++) std::reverse(t[i].begin() + k * 9, t[i].begin() + k * 9 + 9);
+        }
+        auto transpose = [&](int i, int rows_in, int cols_out) {
+            std::vector<float> o(sizes[i]);
+            for (int r = 0; r < rows_in; r++)
+                for (int c = 0; c < cols_out; c++) o[(size_t)c * rows_in + r] = t[i][(size_t)r * cols_out + c];
+            t[i].swap(o);
+        };
+        transpose(8, 4 * S, S);
+        transpose(12, 2 * S, 64);
+        transpose(14, 64, 1);
+    }
+    // engine layout
+    auto al = [](size_t n) { return (n + 63) / 64 * 64; };
+    size_t off[16], total = 0;
+    const size_t psz[14] = {(size_t)1 * 18 * 64, (size_t)2 * 144 * 64, (size_t)4 * 288 * 64, 32, 64, 128,
+                            6 * 128, 6, (size_t)4 * S * S, (size_t)S, (size_t)2 * S * 64, 64, 64, 1};
+    for (int i = 0; i < 14; i++) { off[i] = total; total += al(psz[i]); }
+    std::vector<float> host(total, 0.f);
+    pack_conv(t[0].data(), 4, 32, &host[off[0]]);
+    pack_conv(t[2].data(), 32, 64, &host[off[1]]);
+    pack_conv(t[4].data(), 64, 128, &host[off[2]]);
+    std::copy(t[1].begin(), t[1].end(), &host[off[3]]);
+    std::copy(t[3].begin(), t[3].end(), &host[off[4]]);
+    std::copy(t[5].begin(), t[5].end(), &host[off[5]]);
+    std::copy(t[6].begin(), t[6].end(), &host[off[6]]);             // act_conv1 rows 0-3
+    std::copy(t[10].begin(), t[10].end(), &host[off[6] + 4 * 128]); // val_conv1 rows 4-5
+    std::copy(t[7].begin(), t[7].end(), &host[off[7]]);
+    std::copy(t[11].begin(), t[11].end(), &host[off[7] + 4]);
+    for (int a = 0; a < S; a++)
+        for (int k = 0; k < 4 * S; k++) host[off[8] + (size_t)k * S + a] = t[8][(size_t)a * 4 * S + k];
+    std::copy(t[9].begin(), t[9].end(), &host[off[9]]);
+    for (int o = 0; o < 64; o++)
+        for (int k = 0; k < 2 * S; k++) host[off[10] + (size_t)k * 64 + o] = t[12][(size_t)o * 2 * S + k];
+    std::copy(t[13].begin(), t[13].end(), &host[off[11]]);
+    std::copy(t[14].begin(), t[14].end(), &host[off[12]]);
+    host[off[13]] = t[15][0];
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (!h->d_weights) HIPCHK(h, hipMalloc((void **)&h->d_weights, total * sizeof(float)));
+    HIPCHK(h, hipMemcpy(h->d_weights, host.data(), total * sizeof(float), hipMemcpyHostToDevice));
+    NetWeights &nw = h->st.net;
+    const float *d = h->d_weights;
+    nw.wconv[0] = d + off[0]; nw.wconv[1] = d + off[1]; nw.wconv[2] = d + off[2];
+    nw.bconv[0] = d + off[3]; nw.bconv[1] = d + off[4]; nw.bconv[2] = d + off[5];
+    nw.whead = d + off[6]; nw.bhead = d + off[7];
+    nw.wpfc = d + off[8]; nw.bpfc = d + off[9];
+    nw.wvfc1 = d + off[10]; nw.bvfc1 = d + off[11];
+    nw.wvfc2 = d + off[12]; nw.bvfc2 = d + off[13];
+    h->have_weights = true;
+    return AZG_OK;
+}
+
+// ---------------------------------------------------------------- game control
+extern "C" int azg_reset_games(azg_handle *h, const uint8_t *mask, const uint32_t *seeds, const int64_t *game_ids)
+{
+    if (!h) return AZG_EINVAL;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    const int B = h->cfg.n_games;
+    void *d_mask = nullptr, *d_ids = nullptr;
+    int rc;
+    if (mask) {
+        if ((rc = scratch_get(h, 0, B, &d_mask))) return rc;
+        HIPCHK(h, hipMemcpyAsync(d_mask, mask, B, hipMemcpyHostToDevice, h->stream));
+    }
+    if (game_ids) {
+        if ((rc = scratch_get(h, 1, B * sizeof(long long), &d_ids))) return rc;
+        HIPCHK(h, hipMemcpyAsync(d_ids, game_ids, B * sizeof(long long), hipMemcpyHostToDevice, h->stream));
+    }
+    hipLaunchKernelGGL(reset_kernel, dim3((B + 255) / 256), dim3(256), 0, h->stream, h->st,
+                       (const unsigned char *)d_mask, (const long long *)d_ids);
+    HIPCHK(h, hipGetLastError());
+    for (int g = 0; g < B; g++)
+        if (!mask || mask[g]) {
+            h->rng[g].seed(seeds ? seeds[g] : (uint32_t)g);
+            h->h_drained[g] = 0;
+        }
+    return refresh_mirrors(h);
+}
+
+extern "C" int azg_set_position(azg_handle *h, int slot, const uint64_t stones1[4], const uint64_t stones2[4],
+                                int last_move, int current_player)
+{
+    if (!h || !stones1 || !stones2) return fail(h, AZG_EINVAL, "null argument");
+    if (slot < 0 || slot >= h->cfg.n_games) return fail(h, AZG_EINVAL, "slot %d out of range", slot);
+    if (current_player != 1 && current_player != 2) return fail(h, AZG_EINVAL, "current_player must be 1 or 2");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    unsigned long long w[2 * MAXW];
+    int ply = 0;
+    for (int i = 0; i < MAXW; i++) {
+        if (stones1[i] & stones2[i]) return fail(h, AZG_EINVAL, "a cell is owned by both players");
+        w[i] = stones1[i]; w[MAXW + i] = stones2[i];
+        ply += __builtin_popcountll(stones1[i]) + __builtin_popcountll(stones2[i]);
+    }
+    const int first = (ply & 1) ? 3 - current_player : current_player;
+    const signed char live = 0;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipMemcpy(h->st.bb + (size_t)slot * 2 * MAXW, w, sizeof(w), hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(h->st.ply + slot, &ply, sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(h->st.last_move + slot, &last_move, sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(h->st.first_player + slot, &first, sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(h->st.status + slot, &live, 1, hipMemcpyHostToDevice));
+    return refresh_mirrors(h);
+}
+
+extern "C" int azg_search(azg_handle *h)
+{
+    if (!h) return AZG_EINVAL;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    if (h->cfg.prior_mode == AZG_PRIOR_NET && !h->have_weights)
+        return fail(h, AZG_ENOWEIGHTS, "azg_set_weights must be called before a net-driven search");
+    SearchLaunch sl;
+    if (!pick_search(h->cfg.board_n, h->cfg.prior_mode, &sl)) return fail(h, AZG_EINVAL, "no search kernel");
+    const int grid = (h->cfg.n_games + sl.T - 1) / sl.T;
+    if (h->ev_pending == h->ev_pool.size()) {
+        hipEvent_t a, b;
+        HIPCHK(h, hipEventCreate(&a));
+        HIPCHK(h, hipEventCreate(&b));
+        h->ev_pool.emplace_back(a, b);
+    }
+    auto &ev = h->ev_pool[h->ev_pending];
+    HIPCHK(h, hipEventRecord(ev.first, h->stream));
+    hipLaunchKernelGGL(sl.fn, dim3(grid), dim3(256), sl.lds, h->stream, h->st);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipEventRecord(ev.second, h->stream));
+    h->ev_pending++;
+    return AZG_OK;
+}
+
+extern "C" int azg_root_stats(azg_handle *h, int32_t *visits, double *q, double *prior, int32_t *root_visits)
+{
+    if (!h) return AZG_EINVAL;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    const int B = h->cfg.n_games, S = h->st.S;
+    void *dv, *dq, *dp, *dr;
+    int rc;
+    if ((rc = scratch_get(h, 2, (size_t)B * S * sizeof(int), &dv))) return rc;
+    if ((rc = scratch_get(h, 3, (size_t)B * S * sizeof(double), &dq))) return rc;
+    if ((rc = scratch_get(h, 4, (size_t)B * S * sizeof(double), &dp))) return rc;
+    if ((rc = scratch_get(h, 5, (size_t)B * sizeof(int), &dr))) return rc;
+    hipLaunchKernelGGL(root_stats_kernel, dim3((B + 3) / 4), dim3(256), 0, h->stream, h->st, (int *)dv,
+                       (double *)dq, (double *)dp, (int *)dr);
+    HIPCHK(h, hipGetLastError());
+    if (visits) HIPCHK(h, hipMemcpyAsync(visits, dv, (size_t)B * S * sizeof(int), hipMemcpyDefault, h->stream));
+    if (q) HIPCHK(h, hipMemcpyAsync(q, dq, (size_t)B * S * sizeof(double), hipMemcpyDefault, h->stream));
+    if (prior) HIPCHK(h, hipMemcpyAsync(prior, dp, (size_t)B * S * sizeof(double), hipMemcpyDefault, h->stream));
+    if (root_visits) HIPCHK(h, hipMemcpyAsync(root_visits, dr, (size_t)B * sizeof(int), hipMemcpyDefault, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return harvest_events(h);
+}
+
+static void make_noise(azg_handle *h)
+{
+    const int B = h->cfg.n_games, S = h->st.S;
+    auto work = [&](int g0, int g1) {
+        for (int g = g0; g < g1; g++) {
+            if (h->h_status[g] != 0) continue;
+            const int K = S - h->h_ply[g];
+            if (K <= 0) continue;
+            // np.random.dirichlet(0.1*np.ones(K)) then the uniform of np.random.choice
+            h->rng[g].dirichlet(0.1, K, h->h_noise + (size_t)g * S);
+            h->h_u[g] = h->rng[g].next_double();
+        }
+    };
+    int nthr = (int)std::min<unsigned>(8, std::max(1u, std::thread::hardware_concurrency()));
+    if (B < 64) nthr = 1;
+    if (nthr == 1) { work(0, B); return; }
+    std::vector<std::thread> pool;
+    const int per = (B + nthr - 1) / nthr;
+    for (int i = 0; i < nthr; i++) pool.emplace_back(work, std::min(B, i * per), std::min(B, (i + 1) * per));
+    for (auto &t : pool) t.join();
+}
+
+static int advance_common(azg_handle *h, double temp, const int32_t *given, int flags, int32_t *moves_out, double *pi_out)
+{
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    const int B = h->cfg.n_games, S = h->st.S;
+    if (!(temp > 0.0)) return fail(h, AZG_EINVAL, "temp must be positive");
+    if (flags & ADV_SAMPLE) {
+        make_noise(h);          // runs while the search kernel is still executing
+        HIPCHK(h, hipMemcpyAsync(h->d_noise, h->h_noise, (size_t)B * S * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipMemcpyAsync(h->d_u, h->h_u, (size_t)B * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    } else {
+        for (int g = 0; g < B; g++) h->h_moves[g] = given[g];
+        HIPCHK(h, hipMemcpyAsync(h->d_given, h->h_moves, (size_t)B * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    }
+    hipLaunchKernelGGL(advance_kernel, dim3((B + 3) / 4), dim3(256), 0, h->stream, h->st, temp, h->d_noise,
+                       h->d_u, (flags & ADV_SAMPLE) ? (const int *)nullptr : h->d_given, flags, h->d_moves,
+                       pi_out ? h->d_pi : (double *)nullptr);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipMemcpyAsync(h->h_moves, h->d_moves, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    if (pi_out) HIPCHK(h, hipMemcpyAsync(pi_out, h->d_pi, (size_t)B * S * sizeof(double), hipMemcpyDefault, h->stream));
+    int rc = refresh_mirrors(h);
+    if (moves_out) for (int g = 0; g < B; g++) moves_out[g] = h->h_moves[g];
+    return rc;
+}
+
+extern "C" int azg_sample_and_advance(azg_handle *h, double temp, int32_t *moves_out, double *pi_out)
+{
+    if (!h) return AZG_EINVAL;
+    return advance_common(h, temp, nullptr, ADV_SAMPLE | ADV_RECORD | ADV_BOARD | ADV_REROOT, moves_out, pi_out);
+}
+
+extern "C" int azg_advance(azg_handle *h, const int32_t *moves, int record, double temp)
+{
+    if (!h || !moves) return fail(h, AZG_EINVAL, "null argument");
+    return advance_common(h, temp, moves, (record ? ADV_RECORD : 0) | ADV_BOARD | ADV_REROOT, nullptr, nullptr);
+}
+
+extern "C" int azg_update_with_move(azg_handle *h, const int32_t *moves)
+{
+    if (!h || !moves) return fail(h, AZG_EINVAL, "null argument");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    const int B = h->cfg.n_games;
+    for (int g = 0; g < B; g++) h->h_moves[g] = moves[g];
+    HIPCHK(h, hipMemcpyAsync(h->d_given, h->h_moves, (size_t)B * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(reroot_kernel, dim3((B + 3) / 4), dim3(256), 0, h->stream, h->st, (const int *)h->d_given);
+    HIPCHK(h, hipGetLastError());
+    return refresh_mirrors(h);
+}
+
+extern "C" int azg_status(azg_handle *h, uint8_t *ended, int8_t *winner, int32_t *plies)
+{
+    if (!h) return AZG_EINVAL;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    int rc = refresh_mirrors(h);
+    const int B = h->cfg.n_games;
+    for (int g = 0; g < B; g++) {
+        if (ended) ended[g] = h->h_status[g] == 1;
+        if (winner) winner[g] = h->h_winner[g];
+        if (plies) plies[g] = h->h_ply[g];
+    }
+    return rc;
+}
+
+extern "C" int azg_states(azg_handle *h, float *out)
+{
+    if (!h || !out) return fail(h, AZG_EINVAL, "null argument");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    const int B = h->cfg.n_games, S = h->st.S;
+    void *d;
+    int rc;
+    if ((rc = scratch_get(h, 2, (size_t)B * 4 * S * sizeof(float), &d))) return rc;
+    hipLaunchKernelGGL(states_kernel, dim3(B), dim3(256), 0, h->stream, h->st, (float *)d);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipMemcpyAsync(out, d, (size_t)B * 4 * S * sizeof(float), hipMemcpyDefault, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return AZG_OK;
+}
+
+extern "C" int azg_drain_samples(azg_handle *h, int max_samples, float *states, double *pi, float *z,
+                                 int64_t *game_id, int32_t *ply, int *n_out)
+{
+    if (!h || !n_out) return fail(h, AZG_EINVAL, "null argument");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    const int B = h->cfg.n_games, S = h->st.S;
+    std::vector<int> map_g, map_t;
+    std::vector<int> taken;
+    for (int g = 0; g < B; g++) {
+        if (h->h_status[g] != 1 || h->h_drained[g]) continue;
+        const int cnt = h->h_scount[g];
+        if ((int)map_g.size() + cnt > max_samples) break;
+        for (int t = 0; t < cnt; t++) { map_g.push_back(g); map_t.push_back(t); }
+        taken.push_back(g);
+    }
+    const int n = (int)map_g.size();
+    *n_out = n;
+    for (int g : taken) h->h_drained[g] = 1;
+    if (n == 0) return AZG_OK;
+    void *dg, *dt, *ds, *dp, *dz, *di, *dl;
+    int rc;
+    if ((rc = scratch_get(h, 0, (size_t)n * sizeof(int), &dg))) return rc;
+    if ((rc = scratch_get(h, 1, (size_t)n * sizeof(int), &dt))) return rc;
+    if ((rc = scratch_get(h, 2, (size_t)n * 4 * S * sizeof(float), &ds))) return rc;
+    if ((rc = scratch_get(h, 3, (size_t)n * S * sizeof(double), &dp))) return rc;
+    if ((rc = scratch_get(h, 4, (size_t)n * sizeof(float), &dz))) return rc;
+    if ((rc = scratch_get(h, 5, (size_t)n * sizeof(long long), &di))) return rc;
+    if ((rc = scratch_get(h, 6, (size_t)n * sizeof(int), &dl))) return rc;
+    HIPCHK(h, hipMemcpyAsync(dg, map_g.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(dt, map_t.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(drain_kernel, dim3(n), dim3(64), 0, h->stream, h->st, n, (const int *)dg, (const int *)dt,
+                       states ? (float *)ds : nullptr, pi ? (double *)dp : nullptr, (float *)dz, (long long *)di, (int *)dl);
+    HIPCHK(h, hipGetLastError());
+    if (states) HIPCHK(h, hipMemcpyAsync(states, ds, (size_t)n * 4 * S * sizeof(float), hipMemcpyDefault, h->stream));
+    if (pi) HIPCHK(h, hipMemcpyAsync(pi, dp, (size_t)n * S * sizeof(double), hipMemcpyDefault, h->stream));
+    if (z) HIPCHK(h, hipMemcpyAsync(z, dz, (size_t)n * sizeof(float), hipMemcpyDefault, h->stream));
+    if (game_id) HIPCHK(h, hipMemcpyAsync(game_id, di, (size_t)n * sizeof(long long), hipMemcpyDefault, h->stream));
+    if (ply) HIPCHK(h, hipMemcpyAsync(ply, dl, (size_t)n * sizeof(int), hipMemcpyDefault, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return AZG_OK;
+}
+
+extern "C" int azg_eval_batch(azg_handle *h, const float *states, int n, float *probs, float *values)
+{
+    if (!h || !states || n < 0) return fail(h, AZG_EINVAL, "bad argument");
+    if (!h->have_weights) return fail(h, AZG_ENOWEIGHTS, "azg_set_weights must be called first");
+    if (n == 0) return AZG_OK;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    EvalLaunch el;
+    if (!pick_eval(h->cfg.board_n, &el)) return fail(h, AZG_EINVAL, "no CNN kernel is built for board_n=%d", h->cfg.board_n);
+    const int S = h->st.S;
+    void *ds, *dp, *dv;
+    int rc;
+    if ((rc = scratch_get(h, 2, (size_t)n * 4 * S * sizeof(float), &ds))) return rc;
+    if ((rc = scratch_get(h, 3, (size_t)n * S * sizeof(float), &dp))) return rc;
+    if ((rc = scratch_get(h, 4, (size_t)n * sizeof(float), &dv))) return rc;
+    HIPCHK(h, hipMemcpyAsync(ds, states, (size_t)n * 4 * S * sizeof(float), hipMemcpyDefault, h->stream));
+    hipLaunchKernelGGL(el.fn, dim3((n + el.T - 1) / el.T), dim3(256), el.lds, h->stream, h->st.net,
+                       (const float *)ds, n, (float *)dp, (float *)dv);
+    HIPCHK(h, hipGetLastError());
+    if (probs) HIPCHK(h, hipMemcpyAsync(probs, dp, (size_t)n * S * sizeof(float), hipMemcpyDefault, h->stream));
+    if (values) HIPCHK(h, hipMemcpyAsync(values, dv, (size_t)n * sizeof(float), hipMemcpyDefault, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return AZG_OK;
+}
+
+extern "C" int azg_board_step_batch(azg_handle *h, int n, uint64_t *stones, int32_t *ply, int32_t *last_move,
+                                    const int32_t *moves, const int32_t *player, uint8_t *ended, int8_t *winner,
+                                    float *planes)
+{
+    if (!h || n < 0 || !stones || !ply || !last_move || !moves || !player || !ended || !winner)
+        return fail(h, AZG_EINVAL, "null argument");
+    if (n == 0) return AZG_OK;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    const int S = h->st.S;
+    const size_t sb = (size_t)n * 2 * MAXW * 8, si = (size_t)n * 4;
+    char *d = nullptr;
+    const size_t total = sb + 4 * si + 2 * (size_t)n + 16 + (planes ? (size_t)n * 4 * S * 4 : 0);
+    int rc;
+    if ((rc = scratch_get(h, 7, total + 64, (void **)&d))) return rc;
+    u64 *d_st = (u64 *)d;
+    int *d_ply = (int *)(d + sb), *d_last = d_ply + n, *d_mv = d_last + n, *d_pl = d_mv + n, *d_bad = d_pl + n;
+    float *d_planes = (float *)(d_bad + 4);
+    unsigned char *d_end = (unsigned char *)(d_planes + (planes ? (size_t)n * 4 * S : 0));
+    signed char *d_win = (signed char *)(d_end + n);
+    HIPCHK(h, hipMemcpyAsync(d_st, stones, sb, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(d_ply, ply, si, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(d_last, last_move, si, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(d_mv, moves, si, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(d_pl, player, si, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemsetAsync(d_bad, 0, 16, h->stream));
+    hipLaunchKernelGGL(board_step_kernel, dim3((n + 3) / 4), dim3(256), 0, h->stream, h->st.N, h->st.n_in_row, n,
+                       d_st, d_ply, d_last, (const int *)d_mv, (const int *)d_pl, d_end, d_win,
+                       planes ? d_planes : (float *)nullptr, d_bad);
+    HIPCHK(h, hipGetLastError());
+    int bad = 0;
+    HIPCHK(h, hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(stones, d_st, sb, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(ply, d_ply, si, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(last_move, d_last, si, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(ended, d_end, n, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(winner, d_win, n, hipMemcpyDeviceToHost, h->stream));
+    if (planes) HIPCHK(h, hipMemcpyAsync(planes, d_planes, (size_t)n * 4 * S * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (bad) return fail(h, AZG_EMOVE, "illegal move in batch (occupied cell, out of range, or bad player)");
+    return AZG_OK;
+}
+
+extern "C" int azg_profile(azg_handle *h, int64_t *launches, double *ms, int64_t *playouts)
+{
+    if (!h) return AZG_EINVAL;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    int rc = harvest_events(h);
+    if (rc) return rc;
+    const int B = h->cfg.n_games;
+    std::vector<long long> ev(B);
+    HIPCHK(h, hipMemcpy(ev.data(), h->st.evals, (size_t)B * sizeof(long long), hipMemcpyDeviceToHost));
+    HIPCHK(h, hipMemset(h->st.evals, 0, (size_t)B * sizeof(long long)));
+    long long tot = 0;
+    for (long long v : ev) tot += v;
+    if (launches) *launches = h->prof_launches;
+    if (ms) *ms = h->prof_ms;
+    if (playouts) *playouts = tot;
+    h->prof_launches = 0;
+    h->prof_ms = 0.0;
+    return AZG_OK;
+}

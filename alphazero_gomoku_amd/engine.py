@@ -1,0 +1,241 @@
+"""SelfPlayEngine: numpy-facing wrapper of one libazgomoku handle (one GPU)."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import PRIOR_HASH, PRIOR_NET, PRIOR_UNIFORM32  # noqa: F401
+
+
+def _ptr(a, typ=C.c_void_p):
+    return None if a is None else C.cast(a.ctypes.data, typ) if typ is C.c_void_p else a.ctypes.data_as(typ)
+
+
+class SelfPlayEngine:
+    """B concurrent Gomoku self-play games searched by the HIP engine.
+
+    Restates, batched over games, MCTSPlayer.get_action (mcts_alphaZero.py:212-260)
+    and Game.start_self_play (game.py:360-416) of the reference."""
+
+    def __init__(self, board_n=8, n_in_row=5, n_playout=400, n_games=1, c_puct=5.0, device=0,
+                 prior_mode=PRIOR_NET, arena_nodes=0):
+        self.L = _lib.load()
+        self.N, self.S, self.B = int(board_n), int(board_n) ** 2, int(n_games)
+        self.n_in_row, self.n_playout, self.c_puct = int(n_in_row), int(n_playout), float(c_puct)
+        self.device, self.prior_mode = int(device), int(prior_mode)
+        cfg = _lib.Config(self.N, self.n_in_row, self.n_playout, self.B, self.c_puct, self.device,
+                          self.prior_mode, int(arena_nodes), 0)
+        h = C.c_void_p()
+        rc = self.L.azg_create(C.byref(cfg), C.byref(h))
+        if rc != 0:
+            raise _lib.AzgError(rc, (self.L.azg_last_error(None) or b"").decode())
+        self.h = h
+        self._weights_keepalive = None
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.azg_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        _lib.check(self.h, rc)
+
+    # ---- weights -------------------------------------------------------------
+    def set_weights(self, params, layout=_lib.LAYOUT_TORCH):
+        """params: 16 float32 arrays (numpy) or torch tensors (CPU or this GPU)."""
+        arr = (C.c_void_p * 16)()
+        keep = []
+        for i, p in enumerate(params):
+            if hasattr(p, "data_ptr"):                       # torch tensor
+                t = p.detach().contiguous().float()
+                keep.append(t)
+                arr[i] = t.data_ptr()
+            else:
+                a = np.ascontiguousarray(p, dtype=np.float32)
+                keep.append(a)
+                arr[i] = a.ctypes.data
+        self._chk(self.L.azg_set_weights(self.h, arr, layout))
+        self._weights_keepalive = None                        # the engine holds its own copy
+
+    # ---- game control ----------------------------------------------------------
+    def reset_games(self, seeds=None, mask=None, game_ids=None):
+        seeds_a = None if seeds is None else np.ascontiguousarray(seeds, dtype=np.uint32)
+        mask_a = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
+        ids_a = None if game_ids is None else np.ascontiguousarray(game_ids, dtype=np.int64)
+        for a in (seeds_a, mask_a, ids_a):
+            assert a is None or a.shape == (self.B,)
+        self._chk(self.L.azg_reset_games(
+            self.h, _ptr(mask_a, C.POINTER(C.c_uint8)), _ptr(seeds_a, C.POINTER(C.c_uint32)),
+            _ptr(ids_a, C.POINTER(C.c_int64))))
+
+    def set_position(self, slot, states, last_move, current_player):
+        """states: dict move -> player (the reference Board.states)."""
+        w = [np.zeros(4, dtype=np.uint64), np.zeros(4, dtype=np.uint64)]
+        for m, p in states.items():
+            m = int(m)
+            w[int(p) - 1][m >> 6] |= np.uint64(1) << np.uint64(m & 63)
+        self._chk(self.L.azg_set_position(self.h, int(slot), w[0].ctypes.data_as(C.POINTER(C.c_uint64)),
+                                          w[1].ctypes.data_as(C.POINTER(C.c_uint64)), int(last_move),
+                                          int(current_player)))
+
+    def search(self):
+        self._chk(self.L.azg_search(self.h))
+
+    def root_stats(self):
+        visits = np.zeros((self.B, self.S), dtype=np.int32)
+        q = np.zeros((self.B, self.S))
+        p = np.zeros((self.B, self.S))
+        rn = np.zeros(self.B, dtype=np.int32)
+        self._chk(self.L.azg_root_stats(self.h, _ptr(visits), _ptr(q), _ptr(p), _ptr(rn)))
+        return visits, q, p, rn
+
+    def sample_and_advance(self, temp=1.0, want_pi=True):
+        moves = np.zeros(self.B, dtype=np.int32)
+        pi = np.zeros((self.B, self.S)) if want_pi else None
+        self._chk(self.L.azg_sample_and_advance(
+            self.h, float(temp), moves.ctypes.data_as(C.POINTER(C.c_int32)),
+            None if pi is None else pi.ctypes.data_as(C.POINTER(C.c_double))))
+        return moves, pi
+
+    def advance(self, moves, record=False, temp=1.0):
+        mv = np.ascontiguousarray(moves, dtype=np.int32)
+        assert mv.shape == (self.B,)
+        self._chk(self.L.azg_advance(self.h, mv.ctypes.data_as(C.POINTER(C.c_int32)), int(record), float(temp)))
+
+    def update_with_move(self, moves):
+        mv = np.ascontiguousarray(moves, dtype=np.int32)
+        assert mv.shape == (self.B,)
+        self._chk(self.L.azg_update_with_move(self.h, mv.ctypes.data_as(C.POINTER(C.c_int32))))
+
+    def status(self):
+        ended = np.zeros(self.B, dtype=np.uint8)
+        winner = np.zeros(self.B, dtype=np.int8)
+        plies = np.zeros(self.B, dtype=np.int32)
+        self._chk(self.L.azg_status(self.h, ended.ctypes.data_as(C.POINTER(C.c_uint8)),
+                                    winner.ctypes.data_as(C.POINTER(C.c_int8)),
+                                    plies.ctypes.data_as(C.POINTER(C.c_int32))))
+        return ended.astype(bool), winner, plies
+
+    def states(self):
+        out = np.zeros((self.B, 4, self.N, self.N), dtype=np.float32)
+        self._chk(self.L.azg_states(self.h, _ptr(out)))
+        return out
+
+    def drain_samples(self, max_samples=None):
+        """-> dict(states f32 [n,4,N,N], pi f64 [n,S], z f32 [n], game_id i64 [n], ply i32 [n])."""
+        if max_samples is None:
+            max_samples = self.B * self.S
+        st = np.zeros((max_samples, 4, self.N, self.N), dtype=np.float32)
+        pi = np.zeros((max_samples, self.S))
+        z = np.zeros(max_samples, dtype=np.float32)
+        gid = np.zeros(max_samples, dtype=np.int64)
+        ply = np.zeros(max_samples, dtype=np.int32)
+        n = C.c_int(0)
+        self._chk(self.L.azg_drain_samples(self.h, int(max_samples), _ptr(st), _ptr(pi), _ptr(z), _ptr(gid),
+                                           _ptr(ply), C.byref(n)))
+        k = n.value
+        return dict(states=st[:k], pi=pi[:k], z=z[:k], game_id=gid[:k], ply=ply[:k])
+
+    def drain_samples_device(self, states, pi, z, game_id, ply):
+        """Same, into preallocated torch CUDA tensors; returns the sample count."""
+        n = C.c_int(0)
+        self._chk(self.L.azg_drain_samples(self.h, int(z.shape[0]), C.c_void_p(states.data_ptr()),
+                                           C.c_void_p(pi.data_ptr()), C.c_void_p(z.data_ptr()),
+                                           C.c_void_p(game_id.data_ptr()), C.c_void_p(ply.data_ptr()),
+                                           C.byref(n)))
+        return n.value
+
+    def eval_batch(self, states):
+        st = np.ascontiguousarray(states, dtype=np.float32).reshape(-1, 4, self.N, self.N)
+        n = st.shape[0]
+        probs = np.zeros((n, self.S), dtype=np.float32)
+        vals = np.zeros(n, dtype=np.float32)
+        self._chk(self.L.azg_eval_batch(self.h, _ptr(st), n, _ptr(probs), _ptr(vals)))
+        return probs, vals
+
+    def board_step_batch(self, stones, ply, last_move, moves, player, want_planes=True):
+        """In-place Board.do_move + game_end (+ current_state) on n boards."""
+        n = int(ply.shape[0])
+        assert stones.dtype == np.uint64 and stones.shape == (n, 2, 4) and stones.flags.c_contiguous
+        assert ply.dtype == np.int32 and last_move.dtype == np.int32
+        mv = np.ascontiguousarray(moves, dtype=np.int32)
+        pl = np.ascontiguousarray(player, dtype=np.int32)
+        ended = np.zeros(n, dtype=np.uint8)
+        winner = np.zeros(n, dtype=np.int8)
+        planes = np.zeros((n, 4, self.N, self.N), dtype=np.float32) if want_planes else None
+        i32 = C.POINTER(C.c_int32)
+        self._chk(self.L.azg_board_step_batch(
+            self.h, n, stones.ctypes.data_as(C.POINTER(C.c_uint64)), ply.ctypes.data_as(i32),
+            last_move.ctypes.data_as(i32), mv.ctypes.data_as(i32), pl.ctypes.data_as(i32),
+            ended.ctypes.data_as(C.POINTER(C.c_uint8)), winner.ctypes.data_as(C.POINTER(C.c_int8)),
+            None if planes is None else planes.ctypes.data_as(C.POINTER(C.c_float))))
+        return ended.astype(bool), winner, planes
+
+    def profile(self):
+        """(search launches, summed ms on the engine's stream, summed leaf evaluations) since last call."""
+        a, b, c = C.c_int64(0), C.c_double(0.0), C.c_int64(0)
+        self._chk(self.L.azg_profile(self.h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
+    def stream(self):
+        return self.L.azg_stream(self.h)
+
+    # ---- batched self-play -----------------------------------------------------
+    def play_games(self, n_games_total, temp=1.0, seed0=0, first_game_id=0, game_id_stride=1,
+                   on_samples=None, max_moves=None):
+        """Play `n_games_total` self-play games through the B slots, refilling a slot as
+        soon as its game ends (game k uses seed seed0 + id and id = first_game_id +
+        k * game_id_stride).  Returns dict(games, plies, moves_steps, samples) where
+        samples is the concatenated drain output (or None if on_samples consumed it)."""
+        B = self.B
+        next_k = 0
+        ids = np.zeros(B, dtype=np.int64)
+        mask = np.zeros(B, dtype=np.uint8)
+        seeds = np.zeros(B, dtype=np.uint32)
+        for g in range(B):
+            if next_k < n_games_total:
+                ids[g] = first_game_id + next_k * game_id_stride
+                seeds[g] = (seed0 + ids[g]) & 0xFFFFFFFF
+                mask[g] = 1
+                next_k += 1
+        self.reset_games(seeds=seeds, mask=mask, game_ids=ids)
+        live = mask.astype(bool)
+        done = 0
+        total_plies = 0
+        steps = 0
+        collected = []
+        while done < n_games_total and (max_moves is None or steps < max_moves):
+            self.search()
+            self.sample_and_advance(temp, want_pi=False)
+            steps += 1
+            ended, winner, plies = self.status()
+            fin = ended & live
+            if fin.any():
+                out = self.drain_samples()
+                total_plies += len(out["z"])
+                if on_samples is not None:
+                    on_samples(out)
+                else:
+                    collected.append(out)
+                done += int(fin.sum())
+                mask[:] = 0
+                for g in np.nonzero(fin)[0]:
+                    live[g] = False
+                    if next_k < n_games_total:
+                        ids[g] = first_game_id + next_k * game_id_stride
+                        seeds[g] = (seed0 + ids[g]) & 0xFFFFFFFF
+                        mask[g] = 1
+                        live[g] = True
+                        next_k += 1
+                if mask.any():
+                    self.reset_games(seeds=seeds, mask=mask, game_ids=ids)
+        samples = None
+        if collected:
+            samples = {k: np.concatenate([c[k] for c in collected]) for k in collected[0]}
+        return dict(games=done, plies=total_plies, move_steps=steps, samples=samples)

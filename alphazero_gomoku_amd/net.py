@@ -1,0 +1,128 @@
+"""PolicyValueNet with the reference's surface (policy_value_net_pytorch.py:60-157).
+
+PyTorch only holds the parameters (and, for train_step, the optimiser and autograd);
+every forward used by search or by policy_value / policy_value_fn runs in the HIP
+engine's CNN kernel from a packed copy of those parameters."""
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _lib
+from .engine import SelfPlayEngine
+
+PARAM_ORDER = ["conv1.weight", "conv1.bias", "conv2.weight", "conv2.bias", "conv3.weight", "conv3.bias",
+               "act_conv1.weight", "act_conv1.bias", "act_fc1.weight", "act_fc1.bias",
+               "val_conv1.weight", "val_conv1.bias", "val_fc1.weight", "val_fc1.bias",
+               "val_fc2.weight", "val_fc2.bias"]
+
+
+class Net(nn.Module):
+    """Parameter container with the reference's module names, so state_dicts interchange
+    (policy_value_net_pytorch.py:23-41).  forward() exists for autograd in train_step."""
+
+    def __init__(self, board_width, board_height):
+        super().__init__()
+        s = board_width * board_height
+        self.board_width, self.board_height = board_width, board_height
+        self.conv1 = nn.Conv2d(4, 32, 3, padding=1)
+        self.conv2 = nn.Conv2d(32, 64, 3, padding=1)
+        self.conv3 = nn.Conv2d(64, 128, 3, padding=1)
+        self.act_conv1 = nn.Conv2d(128, 4, 1)
+        self.act_fc1 = nn.Linear(4 * s, s)
+        self.val_conv1 = nn.Conv2d(128, 2, 1)
+        self.val_fc1 = nn.Linear(2 * s, 64)
+        self.val_fc2 = nn.Linear(64, 1)
+
+    def forward(self, x):
+        s = self.board_width * self.board_height
+        x = F.relu(self.conv3(F.relu(self.conv2(F.relu(self.conv1(x))))))
+        a = F.relu(self.act_conv1(x)).reshape(-1, 4 * s)
+        a = F.log_softmax(self.act_fc1(a), dim=1)
+        v = F.relu(self.val_conv1(x)).reshape(-1, 2 * s)
+        v = torch.tanh(self.val_fc2(F.relu(self.val_fc1(v))))
+        return a, v
+
+
+class PolicyValueNet(object):
+    def __init__(self, board_width, board_height, model_file=None, use_gpu=True, device=0):
+        if board_width != board_height:
+            raise ValueError("only square boards are supported by the HIP engine")
+        if not torch.cuda.is_available():
+            raise RuntimeError("PolicyValueNet needs a GPU: the forward pass runs in the HIP engine")
+        self.use_gpu = True
+        self.board_width, self.board_height = board_width, board_height
+        self.l2_const = 1e-4
+        self.device = torch.device("cuda", device)
+        self.policy_value_net = Net(board_width, board_height).to(self.device)
+        self.optimizer = torch.optim.Adam(self.policy_value_net.parameters(), weight_decay=self.l2_const)
+        if model_file:
+            self.policy_value_net.load_state_dict(torch.load(model_file, map_location=self.device, weights_only=True))
+        self.version = 0          # bumped whenever the parameters change
+        self._eval_engine = None
+        self._eval_version = -1
+
+    # ---- parameters ----------------------------------------------------------
+    def param_tensors(self):
+        sd = self.policy_value_net.state_dict()
+        return [sd[k] for k in PARAM_ORDER]
+
+    def load_numpy_params(self, params):
+        """16 float32 arrays in the state_dict order above."""
+        sd = self.policy_value_net.state_dict()
+        for k, p in zip(PARAM_ORDER, params):
+            sd[k].copy_(torch.from_numpy(np.ascontiguousarray(p, dtype=np.float32)).reshape(sd[k].shape))
+        self.version += 1
+
+    def sync_engine(self, engine, have_version):
+        """Push the parameters into `engine` if it holds an older copy; returns the version."""
+        if have_version != self.version:
+            engine.set_weights(self.param_tensors(), _lib.LAYOUT_TORCH)
+        return self.version
+
+    def _engine(self):
+        if self._eval_engine is None:
+            self._eval_engine = SelfPlayEngine(self.board_width, min(5, self.board_width), 1, 1,
+                                               device=self.device.index or 0, arena_nodes=8)
+        self._eval_version = self.sync_engine(self._eval_engine, self._eval_version)
+        return self._eval_engine
+
+    # ---- reference surface -----------------------------------------------------
+    def policy_value(self, state_batch):
+        """policy_value_net_pytorch.py:80-94: (probs [B,S], value [B,1]) as numpy."""
+        probs, vals = self._engine().eval_batch(np.asarray(state_batch, dtype=np.float32))
+        return probs, vals.reshape(-1, 1)
+
+    def policy_value_fn(self, board):
+        """policy_value_net_pytorch.py:96-115: (zip(legal moves, probs), value)."""
+        legal = board.availables
+        st = np.ascontiguousarray(board.current_state().reshape(-1, 4, self.board_width, self.board_height))
+        probs, vals = self._engine().eval_batch(st.astype(np.float32))
+        return zip(legal, probs[0][legal]), float(vals[0])
+
+    def train_step(self, state_batch, mcts_probs, winner_batch, lr):
+        """policy_value_net_pytorch.py:117-148 (loss = MSE(v,z) - mean(pi . log p), Adam with
+        weight decay 1e-4); returns Python floats (the reference's loss.data[0] indexing
+        no longer works on current PyTorch)."""
+        dev = self.device
+        s = torch.as_tensor(np.asarray(state_batch), dtype=torch.float32, device=dev)
+        p = torch.as_tensor(np.asarray(mcts_probs), dtype=torch.float32, device=dev)
+        z = torch.as_tensor(np.asarray(winner_batch), dtype=torch.float32, device=dev)
+        self.optimizer.zero_grad()
+        for group in self.optimizer.param_groups:
+            group['lr'] = lr
+        logp, v = self.policy_value_net(s)
+        value_loss = F.mse_loss(v.view(-1), z)
+        policy_loss = -torch.mean(torch.sum(p * logp, 1))
+        loss = value_loss + policy_loss
+        loss.backward()
+        self.optimizer.step()
+        entropy = -torch.mean(torch.sum(torch.exp(logp) * logp, 1))
+        self.version += 1
+        return float(loss.item()), float(entropy.item())
+
+    def get_policy_param(self):
+        return self.policy_value_net.state_dict()
+
+    def save_model(self, model_file):
+        torch.save(self.get_policy_param(), model_file)

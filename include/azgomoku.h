@@ -1,0 +1,156 @@
+/*
+ * azgomoku.h -- C ABI of libazgomoku.so, the MI355X (gfx950) self-play engine.
+ *
+ * The reference (AbcEric/AlphaZero_Gomoku) is pure Python and has no FFI layer;
+ * its boundary for this path is duck typing between train.py / game.py and
+ * MCTSPlayer / PolicyValueNet.  Each entry point below names the reference
+ * interface it stands in for (file:line relative to the reference tree).
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative AZG_E* code; nothing
+ *     throws across the ABI; azg_last_error() gives the text of the last failure
+ *   - the caller owns every buffer it passes; the library owns all device memory
+ *   - pointers documented "host or device" are copied with hipMemcpyDefault
+ *   - one handle per GPU, one HIP stream per handle, not thread-safe
+ *   - calls are synchronous on return unless documented "asynchronous"
+ *   - cells are numbered move = row * N + col with row 0 at the bottom, as
+ *     game.py:70-80 does; only square boards up to 16x16 are supported
+ */
+#ifndef AZGOMOKU_H
+#define AZGOMOKU_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AZG_OK            0
+#define AZG_EINVAL       -1   /* bad argument / unsupported configuration          */
+#define AZG_EHIP         -2   /* a HIP runtime call failed                         */
+#define AZG_ENOWEIGHTS   -3   /* net-driven search requested before azg_set_weights */
+#define AZG_EARENA       -4   /* a game's tree outgrew its arena (raise arena_nodes) */
+#define AZG_ESTATE       -5   /* call not valid in the current state               */
+#define AZG_EMOVE        -6   /* illegal move (occupied cell / out of range)       */
+
+/* where leaf priors and values come from */
+#define AZG_PRIOR_NET        0   /* policy/value CNN (policy_value_net_pytorch.py:23-57) */
+#define AZG_PRIOR_UNIFORM32  1   /* P = float(1)/float(K), v = 0 (test callback)         */
+#define AZG_PRIOR_HASH       2   /* exact dyadic priors from a position hash (test)      */
+
+/* weight tensor layouts accepted by azg_set_weights */
+#define AZG_LAYOUT_TORCH   0   /* state_dict order of policy_value_net_pytorch.py:31-41 */
+#define AZG_LAYOUT_THEANO  1   /* 16-tensor list of policy_value_net_numpy.py:103-113   */
+
+typedef struct azg_handle azg_handle;
+
+typedef struct azg_config {
+    int32_t board_n;       /* board width == height (game.py:15-16)                   */
+    int32_t n_in_row;      /* game.py:21                                              */
+    int32_t n_playout;     /* MCTS(n_playout) mcts_alphaZero.py:98                    */
+    int32_t n_games;       /* concurrent game slots B                                 */
+    double  c_puct;        /* mcts_alphaZero.py:98                                    */
+    int32_t device;        /* HIP device ordinal                                      */
+    int32_t prior_mode;    /* AZG_PRIOR_*                                             */
+    int32_t arena_nodes;   /* expanded nodes kept per game tree; 0 = 4*n_playout+64   */
+    int32_t reserved;
+} azg_config;
+
+/* MCTSPlayer.__init__ / MCTS.__init__ (mcts_alphaZero.py:98-111,201-203) plus
+ * Board.__init__ / init_board (game.py:14-23,60-68) for n_games boards. */
+int  azg_create(const azg_config *cfg, azg_handle **out);
+void azg_destroy(azg_handle *h);
+const char *azg_last_error(const azg_handle *h);      /* h may be NULL: create errors */
+
+/* PolicyValueNet.__init__(model_file) / load_state_dict
+ * (policy_value_net_pytorch.py:76-78; numpy twin policy_value_net_numpy.py:87-90).
+ * ptrs: 16 float32 tensors, host or device; repacked into the engine's own copy. */
+int azg_set_weights(azg_handle *h, const float *const ptrs[16], int layout);
+
+/* Board.init_board + MCTSPlayer.reset_player (game.py:60-68, mcts_alphaZero.py:208-209)
+ * for every slot with mask[g] != 0 (mask NULL = all).  seeds[g] seeds that game's
+ * numpy-legacy RandomState (np.random.seed, used by mcts_alphaZero.py:236-240);
+ * game_ids[g] (may be NULL) is an opaque tag returned by azg_drain_samples. */
+int azg_reset_games(azg_handle *h, const uint8_t *mask, const uint32_t *seeds,
+                    const int64_t *game_ids);
+
+/* Put slot `slot` into an arbitrary position (the board object a caller hands to
+ * MCTSPlayer.get_action, mcts_alphaZero.py:212-216).  stones1/stones2: bit m of word
+ * m/64 set when player 1/2 owns cell m (4 words each).  The search tree of the slot
+ * is left untouched. */
+int azg_set_position(azg_handle *h, int slot, const uint64_t stones1[4],
+                     const uint64_t stones2[4], int last_move, int current_player);
+
+/* MCTS.get_move_probs' playout loop (mcts_alphaZero.py:161-163) for every live
+ * slot: n_playout sequential playouts per game, all games advancing together.
+ * Asynchronous: returns after enqueueing; later calls on the handle order after it. */
+int azg_search(azg_handle *h);
+
+/* Root statistics after azg_search (mcts_alphaZero.py:166-168): per slot and per
+ * cell the child's visit count (0 for occupied cells), optionally Q and P, and the
+ * root's own visit count.  Outputs host or device; any may be NULL. */
+int azg_root_stats(azg_handle *h, int32_t *visits /*[B,S]*/, double *q /*[B,S]*/,
+                   double *prior /*[B,S]*/, int32_t *root_visits /*[B]*/);
+
+/* MCTSPlayer.get_action with is_selfplay=1 (mcts_alphaZero.py:216-242) followed by
+ * the bookkeeping of Game.start_self_play (game.py:381-391) for every live slot:
+ * pi = softmax(log(visits+1e-10)/temp); move ~ 0.75*pi + 0.25*Dirichlet(0.1) drawn
+ * from the slot's RandomState; the (state, pi, player) sample is recorded; the move
+ * is played; the tree is re-rooted at the move (update_with_move, :183-192); the
+ * game-end test runs.  moves_out [B] (-1 for slots not live), pi_out [B,S]: host
+ * pointers, may be NULL. */
+int azg_sample_and_advance(azg_handle *h, double temp, int32_t *moves_out, double *pi_out);
+
+/* Same bookkeeping with caller-chosen moves (host pointer, [B], -1 = leave slot
+ * alone): Board.do_move + MCTS.update_with_move(move).  record != 0 also stores the
+ * training sample with pi from the current root visits at `temp`. */
+int azg_advance(azg_handle *h, const int32_t *moves, int record, double temp);
+
+/* MCTS.update_with_move (mcts_alphaZero.py:183-192) alone, board untouched:
+ * moves[g] >= 0 re-roots at that child (fresh root if it is no child), -1 discards
+ * the tree (reset_player), -2 leaves the slot alone.  Host pointer [B]. */
+int azg_update_with_move(azg_handle *h, const int32_t *moves);
+
+/* Board.game_end / get_current_player for every slot (game.py:162-172):
+ * ended[g] (0/1), winner[g] (1, 2 or -1), plies[g] = len(states).  Host pointers,
+ * any may be NULL. */
+int azg_status(azg_handle *h, uint8_t *ended, int8_t *winner, int32_t *plies);
+
+/* Board.current_state for every slot (game.py:92-116): float32 [B,4,N,N], host or
+ * device. */
+int azg_states(azg_handle *h, float *out);
+
+/* The (state, mcts_probs, winners_z) tuples Game.start_self_play returns
+ * (game.py:393-416) for every finished, not yet drained game, slot order then ply
+ * order.  states f32 [n,4,N,N], pi f64 [n,S], z f32 [n], game_id i64 [n], ply i32 [n]
+ * (host or device, any may be NULL).  At most max_samples are written; *n_out gets
+ * the count.  A game whose samples do not fit is left for the next call. */
+int azg_drain_samples(azg_handle *h, int max_samples, float *states, double *pi, float *z,
+                      int64_t *game_id, int32_t *ply, int *n_out);
+
+/* PolicyValueNet.policy_value (policy_value_net_pytorch.py:80-94): states f32
+ * [n,4,N,N] -> probs f32 [n,S] (exp of the log-softmax), values f32 [n].  Host or
+ * device pointers. */
+int azg_eval_batch(azg_handle *h, const float *states, int n, float *probs, float *values);
+
+/* Stateless batched Board.do_move + game_end + current_state (game.py:92-127,
+ * 162-169) for n independent boards: stones [n,2,4] words and ply/last_move [n] are
+ * updated in place, moves [n] are played by `player[i]` (1 or 2; the side to move
+ * afterwards is the other one), ended/winner [n] and planes f32 [n,4,N,N] are
+ * produced.  All host pointers; planes may be NULL.  Illegal moves give AZG_EMOVE. */
+int azg_board_step_batch(azg_handle *h, int n, uint64_t *stones, int32_t *ply,
+                         int32_t *last_move, const int32_t *moves, const int32_t *player,
+                         uint8_t *ended, int8_t *winner, float *planes);
+
+/* Timing of the search kernel, measured with HIP events on the handle's stream:
+ * number of launches since the last call, summed milliseconds, and summed leaf
+ * evaluations (playouts that reached the CNN).  Resets the counters. */
+int azg_profile(azg_handle *h, int64_t *launches, double *ms, int64_t *playouts);
+
+/* The handle's HIP stream (hipStream_t), for callers that record their own events. */
+void *azg_stream(azg_handle *h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -518,6 +518,18 @@ int azo_mcts_get_move_probs(azo_mcts *m, const azo_board *state, double temp,
     return k;
 }
 
+/* Root children statistics without running playouts (inspection helper). */
+int azo_mcts_root_children(const azo_mcts *m, int *acts, int *visits, double *q, double *prior)
+{
+    const node *root = &m->nodes[m->root];
+    int k = root->first_child >= 0 ? root->n_children : 0;
+    for (int i = 0; i < k; i++) {
+        const node *ch = &m->nodes[root->first_child + i];
+        acts[i] = ch->action; visits[i] = ch->n_visits; q[i] = ch->Q; prior[i] = ch->P;
+    }
+    return k;
+}
+
 /* Copy the subtree below `src` into a fresh pool (keeps memory bounded; the
  * reference simply drops the Python references to the rest of the tree). */
 static void copy_subtree(const node *old, node **dst, long *n, long *cap, int src_first,

@@ -80,6 +80,7 @@ void      azo_mcts_free(azo_mcts *m);
 int  azo_mcts_get_move_probs(azo_mcts *m, const azo_board *state, double temp,
                              int *acts, int *visits, double *q, double *prior, double *probs);
 void azo_mcts_update_with_move(azo_mcts *m, int last_move);
+int  azo_mcts_root_children(const azo_mcts *m, int *acts, int *visits, double *q, double *prior);
 int  azo_mcts_root_visits(const azo_mcts *m);
 long azo_mcts_node_count(const azo_mcts *m);
 

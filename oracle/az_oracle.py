@@ -80,6 +80,8 @@ def lib():
                                           C.POINTER(C.c_double), C.POINTER(C.c_double),
                                           C.POINTER(C.c_double)]
     L.azo_mcts_update_with_move.argtypes = [C.c_void_p, C.c_int]
+    L.azo_mcts_root_children.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                         C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.azo_mcts_root_visits.argtypes = [C.c_void_p]
     L.azo_self_play.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_double,
                                 C.c_int, C.c_double, C.c_uint32, C.POINTER(GameRecord)]
@@ -205,6 +207,14 @@ class OracleMCTS:
 
     def update_with_move(self, move):
         lib().azo_mcts_update_with_move(self.m, int(move))
+
+    def root_children(self):
+        acts = (C.c_int * MAX_CELLS)()
+        visits = (C.c_int * MAX_CELLS)()
+        q = (C.c_double * MAX_CELLS)()
+        pr = (C.c_double * MAX_CELLS)()
+        k = lib().azo_mcts_root_children(self.m, acts, visits, q, pr)
+        return np.array(acts[:k]), np.array(visits[:k]), np.array(q[:k]), np.array(pr[:k])
 
     def root_visits(self):
         return lib().azo_mcts_root_visits(self.m)

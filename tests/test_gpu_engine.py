@@ -1,0 +1,256 @@
+"""GPU parity tests: the HIP engine, called through the C ABI, against the CPU oracle and
+the golden vectors produced from the reference.  Integer results (visit counts, moves,
+winners, planes) must match bit-exactly; tree Q values bit-exactly (IEEE double, same
+operation order); pi within 1e-12; CNN outputs within 1e-4 (float32)."""
+import os
+
+import numpy as np
+import pytest
+
+import helpers
+
+pytestmark = pytest.mark.gpu
+G = helpers.GOLDEN
+
+
+def load(name):
+    return np.load(os.path.join(G, name), allow_pickle=True)
+
+
+@pytest.fixture(scope="module")
+def az():
+    import alphazero_gomoku_amd as pkg
+    return pkg
+
+
+def stones_of(moves, first=1):
+    st = {}
+    for i, m in enumerate(moves):
+        st[int(m)] = first if i % 2 == 0 else 3 - first
+    return st
+
+
+MODES = {"uniform32": 1, "hash": 2}
+
+
+def test_rules_replay_batched(az):
+    """Board.do_move / game_end / current_state for every golden game, all games of one
+    board size stepping together through azg_board_step_batch."""
+    d = load("g1_rules.npz")
+    meta, moves, ends, winners, states = d["meta"], d["moves"], d["ends"], d["winners"], d["states"]
+    games = []
+    mo = so = 0
+    for (n, k, ln) in meta:
+        games.append((int(n), int(k), moves[mo:mo + ln], ends[mo:mo + ln], winners[mo:mo + ln],
+                      states[so:so + 8 * n * n].reshape(2, 4, n, n)))
+        mo += ln
+        so += 8 * n * n
+    for (n, k) in sorted(set((g[0], g[1]) for g in games)):
+        sel = [g for g in games if g[0] == n and g[1] == k]
+        eng = az.SelfPlayEngine(n, k, 1, 1, prior_mode=az.PRIOR_HASH)
+        nb = len(sel)
+        st = np.zeros((nb, 2, 4), dtype=np.uint64)
+        ply = np.zeros(nb, dtype=np.int32)
+        last = np.full(nb, -1, dtype=np.int32)
+        maxlen = max(len(g[2]) for g in sel)
+        done_len = np.array([len(g[2]) for g in sel])
+        for t in range(maxlen):
+            act = np.nonzero(done_len > t)[0]
+            sub_st = np.ascontiguousarray(st[act])
+            sub_ply = np.ascontiguousarray(ply[act])
+            sub_last = np.ascontiguousarray(last[act])
+            mv = np.array([sel[i][2][t] for i in act], dtype=np.int32)
+            pl = np.array([1 + t % 2] * len(act), dtype=np.int32)
+            e, w, planes = eng.board_step_batch(sub_st, sub_ply, sub_last, mv, pl)
+            st[act], ply[act], last[act] = sub_st, sub_ply, sub_last
+            for j, i in enumerate(act):
+                assert (int(e[j]), int(w[j])) == (int(sel[i][3][t]), int(sel[i][4][t])), (n, k, i, t)
+                ln = len(sel[i][2])
+                if t + 1 == ln:
+                    assert np.array_equal(planes[j], sel[i][5][1].astype(np.float32)), (n, k, i, "final")
+                if t + 1 == ln // 2 and ln // 2 > 0:
+                    assert np.array_equal(planes[j], sel[i][5][0].astype(np.float32)), (n, k, i, "mid")
+        with pytest.raises(az._lib.AzgError):
+            eng.board_step_batch(np.ascontiguousarray(st[:1]), np.ascontiguousarray(ply[:1]),
+                                 np.ascontiguousarray(last[:1]), np.array([sel[0][2][0]], dtype=np.int32),
+                                 np.array([1], dtype=np.int32))
+        eng.close()
+
+
+def test_tree_fixtures_bit_exact(az):
+    """Root statistics after n playouts (fresh root, then re-rooted and searched again)
+    against the reference's own MCTS with exact synthetic callbacks."""
+    for c in load("g2_tree.npz")["cases"]:
+        n, k = int(c["n"]), int(c["k"])
+        eng = az.SelfPlayEngine(n, k, int(c["n_playout"]), 1, float(c["c_puct"]), prior_mode=MODES[c["cb"]])
+        eng.reset_games()
+        prefix = [int(m) for m in c["prefix"]]
+        st = stones_of(prefix)
+        cur = 1 + len(prefix) % 2
+        eng.set_position(0, st, prefix[-1] if prefix else -1, cur)
+        eng.search()
+        visits, q, p, rn = eng.root_stats()
+        acts = c["acts"]
+        tag = (n, c["cb"], int(c["n_playout"]), tuple(prefix))
+        assert np.array_equal(visits[0][acts], c["visits"]), tag
+        assert visits[0].sum() == c["visits"].sum(), tag
+        assert np.array_equal(q[0][acts], c["q"]), tag
+        assert np.array_equal(p[0][acts], c["p"]), tag
+        mv = int(c["move"])
+        if len(c["acts2"]):
+            moves = np.array([mv], dtype=np.int32)
+            eng.advance(moves)
+            _, _, _, rn = eng.root_stats()
+            assert rn[0] == c["root_n_before"], tag
+            eng.search()
+            visits, q, p, rn = eng.root_stats()
+            assert np.array_equal(visits[0][c["acts2"]], c["visits2"]), tag
+            assert np.array_equal(q[0][c["acts2"]], c["q2"]), tag
+            assert rn[0] == c["root_n_after"], tag
+        eng.close()
+
+
+def test_seeded_games_match_reference(az):
+    """Whole seeded self-play games (numpy-legacy Dirichlet stream, tree reuse) against the
+    reference's recorded games: moves, visit counts per move, pi, z, winner, states."""
+    games = [g for g in load("g3_games.npz")["games"] if g["cb"] in MODES]
+    for g in games:
+        n, k = int(g["n"]), int(g["k"])
+        eng = az.SelfPlayEngine(n, k, int(g["n_playout"]), 1, float(g["c_puct"]), prior_mode=MODES[g["cb"]])
+        eng.reset_games(seeds=np.array([g["seed"]], dtype=np.uint32))
+        tag = (n, g["cb"], int(g["n_playout"]), int(g["seed"]))
+        for t in range(len(g["moves"])):
+            eng.search()
+            visits, _, _, _ = eng.root_stats()
+            assert np.array_equal(visits[0], g["visits"][t]), (tag, t)
+            moves, pi = eng.sample_and_advance(float(g["temp"]))
+            assert moves[0] == g["moves"][t], (tag, t)
+            np.testing.assert_allclose(pi[0], g["pi"][t], rtol=0, atol=1e-12)
+        ended, winner, plies = eng.status()
+        assert ended[0] and winner[0] == g["winner"] and plies[0] == len(g["moves"]), tag
+        s = eng.drain_samples()
+        assert np.array_equal(s["z"], g["z"].astype(np.float32)), tag
+        assert np.array_equal(s["states"], g["states"].astype(np.float32)), tag
+        np.testing.assert_allclose(s["pi"], g["pi"], rtol=0, atol=1e-12)
+        assert np.array_equal(s["ply"], np.arange(len(g["moves"])))
+        eng.close()
+
+
+def test_cnn_against_reference_and_oracle(az, oracle):
+    """azg_eval_batch (HIP CNN, float32 MFMA) against the reference's PyTorch and numpy
+    nets (golden) and the CPU oracle: |dp| and |dv| below 1e-4."""
+    d = load("g4_cnn.npz")
+    for (n, k, count, scale, seed) in d["spec"]:
+        n, k, count, seed = int(n), int(k), int(count), int(seed)
+        tag = "%d_s%g" % (n, scale)
+        params = helpers.make_params(n, seed=seed, scale=float(scale))
+        eng = az.SelfPlayEngine(n, k, 1, 1)
+        eng.set_weights(params)
+        states = d["states_" + tag].astype(np.float32)
+        probs, vals = eng.eval_batch(states)
+        assert np.abs(probs - d["probs_torch_" + tag]).max() < 1e-4, tag
+        assert np.abs(vals - d["value_torch_" + tag]).max() < 1e-4, tag
+        assert np.abs(probs - d["probs_numpy_" + tag]).max() < 1e-4, tag
+        assert np.abs(vals - d["value_numpy_" + tag]).max() < 1e-4, tag
+        net = oracle.OracleNet(n, n, params, precise=True)
+        for i in range(0, count, 7):
+            po, vo = net.forward(states[i].astype(np.float64))
+            assert np.abs(probs[i] - po).max() < 1e-4 and abs(vals[i] - vo) < 1e-4
+        # the theano-layout entry point must give the same numbers
+        eng2 = az.SelfPlayEngine(n, k, 1, 1)
+        eng2.set_weights(helpers.torch_to_theano_layout(params), layout=az._lib.LAYOUT_THEANO)
+        p2, v2 = eng2.eval_batch(states)
+        assert np.array_equal(p2, probs) and np.array_equal(v2, vals)
+        # batch-position invariance: a state evaluates to the same bits wherever it sits
+        p3, v3 = eng.eval_batch(states[::-1].copy())
+        assert np.array_equal(p3[::-1], probs) and np.array_equal(v3[::-1], vals)
+        eng.close()
+        eng2.close()
+
+
+def test_net_search_bit_exact_vs_oracle_with_gpu_priors(az, oracle):
+    """Net-driven search: the CPU oracle's MCTS, fed the GPU CNN's own float32 outputs
+    through a callback, must reproduce the engine's visit counts bit-exactly."""
+    for (n, k, npo, prefix) in [(6, 4, 120, []), (8, 5, 200, []), (8, 5, 150, [27, 28, 35, 36, 20, 21])]:
+        params = helpers.make_params(n, seed=100 + n, scale=2.0)
+        eng = az.SelfPlayEngine(n, k, npo, 1)
+        eng.set_weights(params)
+        ev = az.SelfPlayEngine(n, k, 1, 1)
+        ev.set_weights(params)
+        eng.reset_games()
+        st = stones_of(prefix)
+        eng.set_position(0, st, prefix[-1] if prefix else -1, 1 + len(prefix) % 2)
+        eng.search()
+        visits, q, p, rn = eng.root_stats()
+
+        def policy(b):
+            ob = oracle.OracleBoard(n, n, k)
+            ob.b = b
+            pr, v = ev.eval_batch(ob.current_state().astype(np.float32))
+            return [float(x) for x in pr[0]], float(v[0])
+        ob = oracle.OracleBoard(n, n, k)
+        ob.init_board()
+        for m in prefix:
+            ob.do_move(m)
+        t = oracle.OracleMCTS(policy, c_puct=5, n_playout=npo)
+        acts, ovis, oq, op, _ = t.get_move_probs(ob, temp=1.0)
+        assert np.array_equal(visits[0][acts], ovis), (n, npo)
+        assert np.array_equal(q[0][acts], oq), (n, npo)
+        assert np.array_equal(p[0][acts], op), (n, npo)
+        eng.close()
+        ev.close()
+
+
+def test_batched_games_are_independent_of_batching(az, oracle):
+    """Many games in flight: each slot's game must equal the oracle's game for that seed,
+    whatever slot or batch it ran in (hash priors; bit-exact moves and visit counts)."""
+    n, k, npo = 8, 5, 64
+    eng = az.SelfPlayEngine(n, k, npo, 37, prior_mode=az.PRIOR_HASH)
+    res = eng.play_games(60, temp=1.0, seed0=1000)
+    s = res["samples"]
+    assert res["games"] == 60
+    for gid in (0, 1, 17, 36, 37, 59):
+        r = oracle.self_play(n, k, "hash", 5, npo, 1.0, 1000 + gid)
+        sel = np.nonzero(s["game_id"] == gid)[0]
+        sel = sel[np.argsort(s["ply"][sel])]
+        assert len(sel) == len(r["moves"]), gid
+        np.testing.assert_allclose(s["pi"][sel], r["pi"], rtol=0, atol=1e-12)
+        assert np.array_equal(s["z"][sel], r["z"].astype(np.float32)), gid
+        assert np.array_equal(s["states"][sel], r["states"].astype(np.float32)), gid
+    eng.close()
+
+
+def test_sqrt_is_correctly_rounded_on_device(az):
+    """The PUCT term uses sqrt(parent visits) in double; the tree fixtures above cover it
+    up to a few hundred visits, this covers larger counts through a long search."""
+    eng = az.SelfPlayEngine(6, 4, 3000, 1, prior_mode=az.PRIOR_HASH, arena_nodes=3100)
+    eng.reset_games()
+    eng.search()
+    visits, q, _, rn = eng.root_stats()
+    from oracle import az_oracle
+    ob = az_oracle.OracleBoard(6, 6, 4)
+    ob.init_board()
+    t = az_oracle.OracleMCTS("hash", c_puct=5, n_playout=3000)
+    acts, ovis, oq, _, _ = t.get_move_probs(ob, temp=1.0)
+    assert rn[0] == 3000 and np.array_equal(visits[0][acts], ovis) and np.array_equal(q[0][acts], oq)
+    eng.close()
+
+
+def test_error_paths(az):
+    with pytest.raises(az._lib.AzgError):
+        az.SelfPlayEngine(4, 5, 10, 1)                       # board smaller than n_in_row
+    with pytest.raises(az._lib.AzgError):
+        az.SelfPlayEngine(7, 5, 10, 1)                       # no CNN kernel for 7x7
+    eng = az.SelfPlayEngine(8, 5, 10, 1)
+    eng.reset_games()
+    with pytest.raises(az._lib.AzgError) as e:
+        eng.search()                                         # weights missing
+    assert e.value.code == -3
+    eng.close()
+    eng = az.SelfPlayEngine(6, 4, 400, 1, prior_mode=az.PRIOR_HASH, arena_nodes=16)
+    eng.reset_games()
+    eng.search()
+    with pytest.raises(az._lib.AzgError) as e:
+        eng.status()                                         # arena overflow is reported
+    assert e.value.code == -4
+    eng.close()

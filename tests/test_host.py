@@ -1,0 +1,110 @@
+"""CPU-only checks of the host side: the C-ABI library loads and exports every symbol the
+header declares, the host Board mirrors the reference's rules (golden vectors), and the
+product refuses to run without a GPU instead of falling back to anything."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+import helpers
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    import alphazero_gomoku_amd as az
+    hdr = open(os.path.join(ROOT, "include", "azgomoku.h")).read()
+    declared = sorted(set(re.findall(r"\b(azg_[a-z_]+)\s*\(", hdr)))
+    assert declared, "no declarations found"
+    lib = az._lib.load()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert sorted(az._lib.SYMBOLS) == declared
+
+
+def test_no_cpu_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import alphazero_gomoku_amd as az
+    with pytest.raises(az._lib.AzgError):
+        az.SelfPlayEngine(8, 5, 10, 1)
+    with pytest.raises(RuntimeError):
+        az.PolicyValueNet(8, 8)
+    with pytest.raises(TypeError):
+        az.MCTSPlayer(lambda board: ([], 0.0))
+
+
+def test_host_board_matches_reference_rules():
+    import alphazero_gomoku_amd as az
+    d = np.load(os.path.join(helpers.GOLDEN, "g1_rules.npz"))
+    meta, moves, ends, winners, states = d["meta"], d["moves"], d["ends"], d["winners"], d["states"]
+    mo = so = 0
+    for (n, k, ln) in meta:
+        b = az.Board(width=int(n), height=int(n), n_in_row=int(k))
+        b.init_board()
+        mid = None
+        for t in range(ln):
+            if t == ln // 2:
+                mid = b.current_state()
+            b.do_move(int(moves[mo + t]))
+            assert b.game_end() == (bool(ends[mo + t]), int(winners[mo + t])), (n, k, t)
+            assert len(b.availables) == n * n - t - 1 and b.last_move == moves[mo + t]
+        if mid is None:
+            mid = b.current_state()
+        exp = states[so:so + 8 * n * n].reshape(2, 4, n, n)
+        assert np.array_equal(mid, exp[0]) and np.array_equal(b.current_state(), exp[1])
+        mo += ln
+        so += 8 * n * n
+
+
+def test_host_board_errors_and_helpers():
+    import alphazero_gomoku_amd as az
+    b = az.Board(width=3, height=3, n_in_row=4)
+    with pytest.raises(Exception):
+        b.init_board()
+    b = az.Board(width=6, height=6, n_in_row=4)
+    b.init_board(start_player=1)
+    assert b.current_player == 2 and b.get_current_player() == 2
+    b.do_move(7)
+    with pytest.raises(ValueError):
+        b.do_move(7)
+    assert b.move_to_location(7) == [1, 1] and b.location_to_move([1, 1]) == 7
+    assert b.location_to_move([9, 9]) == -1 and b.location_to_move([1]) == -1
+    assert b.states == {7: 2} and b.current_player == 1
+
+
+def _gather_worker(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+    from alphazero_gomoku_amd import dist as azdist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n = 3 + 2 * rank                      # ragged: 3 and 5 samples
+    first, stride, count = azdist.shard_game_ids(rank, world, 7)
+    t = {"z": torch.arange(n, dtype=torch.float32) + 100 * rank,
+         "pi": torch.full((n, 4), float(rank), dtype=torch.float64),
+         "game_id": torch.arange(n, dtype=torch.int64) * stride + first}
+    out = azdist.gather_samples(t)
+    q.put((rank, out["z"].tolist(), out["pi"].shape, out["game_id"].tolist(), (first, stride, count)))
+    dist.destroy_process_group()
+
+
+def test_sample_gather_two_ranks_gloo():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_gather_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+    exp_z = [0.0, 1.0, 2.0, 100.0, 101.0, 102.0, 103.0, 104.0]
+    for rank, z, pishape, gid, shard in res:
+        assert z == exp_z and tuple(pishape) == (8, 4)
+        assert gid == [0, 2, 4, 1, 3, 5, 7, 9]
+    assert res[0][4] == (0, 2, 4) and res[1][4] == (1, 2, 3)
