@@ -127,10 +127,16 @@ class SelfPlayEngine:
         self._chk(self.L.azg_states(self.h, _ptr(out)))
         return out
 
+    def pending_samples(self, ended=None, plies=None):
+        """Upper bound of the samples azg_drain_samples would return now."""
+        if ended is None:
+            ended, _, plies = self.status()
+        return int(plies[ended].sum())
+
     def drain_samples(self, max_samples=None):
         """-> dict(states f32 [n,4,N,N], pi f64 [n,S], z f32 [n], game_id i64 [n], ply i32 [n])."""
         if max_samples is None:
-            max_samples = self.B * self.S
+            max_samples = max(1, self.pending_samples())
         st = np.zeros((max_samples, 4, self.N, self.N), dtype=np.float32)
         pi = np.zeros((max_samples, self.S))
         z = np.zeros(max_samples, dtype=np.float32)
@@ -190,52 +196,84 @@ class SelfPlayEngine:
     def play_games(self, n_games_total, temp=1.0, seed0=0, first_game_id=0, game_id_stride=1,
                    on_samples=None, max_moves=None):
         """Play `n_games_total` self-play games through the B slots, refilling a slot as
-        soon as its game ends (game k uses seed seed0 + id and id = first_game_id +
-        k * game_id_stride).  Returns dict(games, plies, moves_steps, samples) where
-        samples is the concatenated drain output (or None if on_samples consumed it)."""
-        B = self.B
-        next_k = 0
-        ids = np.zeros(B, dtype=np.int64)
-        mask = np.zeros(B, dtype=np.uint8)
-        seeds = np.zeros(B, dtype=np.uint32)
-        for g in range(B):
-            if next_k < n_games_total:
-                ids[g] = first_game_id + next_k * game_id_stride
-                seeds[g] = (seed0 + ids[g]) & 0xFFFFFFFF
-                mask[g] = 1
-                next_k += 1
-        self.reset_games(seeds=seeds, mask=mask, game_ids=ids)
-        live = mask.astype(bool)
-        done = 0
-        total_plies = 0
-        steps = 0
+        soon as its game ends (game k has id = first_game_id + k * game_id_stride and draws
+        its noise from numpy's legacy RandomState seeded with seed0 + id).  Returns
+        dict(games, plies, move_steps, samples); samples is the concatenated drain output
+        (None if on_samples consumed it)."""
         collected = []
-        while done < n_games_total and (max_moves is None or steps < max_moves):
-            self.search()
-            self.sample_and_advance(temp, want_pi=False)
-            steps += 1
-            ended, winner, plies = self.status()
-            fin = ended & live
-            if fin.any():
-                out = self.drain_samples()
-                total_plies += len(out["z"])
-                if on_samples is not None:
-                    on_samples(out)
-                else:
-                    collected.append(out)
-                done += int(fin.sum())
-                mask[:] = 0
-                for g in np.nonzero(fin)[0]:
-                    live[g] = False
-                    if next_k < n_games_total:
-                        ids[g] = first_game_id + next_k * game_id_stride
-                        seeds[g] = (seed0 + ids[g]) & 0xFFFFFFFF
-                        mask[g] = 1
-                        live[g] = True
-                        next_k += 1
-                if mask.any():
-                    self.reset_games(seeds=seeds, mask=mask, game_ids=ids)
+        sink = on_samples if on_samples is not None else collected.append
+        run = SelfPlayRunner(self, temp, seed0, first_game_id, game_id_stride, n_games_total, sink)
+        run.start()
+        while run.games_done < n_games_total and (max_moves is None or run.steps < max_moves):
+            run.step()
         samples = None
         if collected:
             samples = {k: np.concatenate([c[k] for c in collected]) for k in collected[0]}
-        return dict(games=done, plies=total_plies, move_steps=steps, samples=samples)
+        return dict(games=run.games_done, plies=run.plies_done, move_steps=run.steps, samples=samples)
+
+
+class SelfPlayRunner:
+    """Keeps the B slots of an engine busy: every step() is one move for every live game
+    (MCTSPlayer.get_action + the per-move part of Game.start_self_play); finished games are
+    drained and their slots restarted with the next game id until `total` games have been
+    started (total=None: without limit)."""
+
+    def __init__(self, engine, temp=1.0, seed0=0, first_game_id=0, game_id_stride=1, total=None,
+                 on_samples=None, device_samples=False):
+        self.e, self.temp, self.seed0 = engine, float(temp), int(seed0)
+        self.first, self.stride, self.total = int(first_game_id), int(game_id_stride), total
+        self.on_samples, self.device_samples = on_samples, device_samples
+        B = engine.B
+        self.ids = np.zeros(B, dtype=np.int64)
+        self.seeds = np.zeros(B, dtype=np.uint32)
+        self.live = np.zeros(B, dtype=bool)
+        self.next_k = 0
+        self.games_done = self.plies_done = self.steps = 0
+
+    def _assign(self, slots):
+        mask = np.zeros(self.e.B, dtype=np.uint8)
+        for g in slots:
+            if self.total is not None and self.next_k >= self.total:
+                self.live[g] = False
+                continue
+            self.ids[g] = self.first + self.next_k * self.stride
+            self.seeds[g] = (self.seed0 + int(self.ids[g])) & 0xFFFFFFFF
+            mask[g] = 1
+            self.live[g] = True
+            self.next_k += 1
+        if mask.any():
+            self.e.reset_games(seeds=self.seeds, mask=mask, game_ids=self.ids)
+
+    def start(self):
+        self._assign(range(self.e.B))
+
+    def step(self):
+        """One move for every live slot; returns (games finished, samples drained)."""
+        e = self.e
+        e.search()
+        e.sample_and_advance(self.temp, want_pi=False)
+        self.steps += 1
+        ended, _, plies = e.status()
+        fin = ended & self.live
+        nfin = int(fin.sum())
+        nsamp = 0
+        if nfin:
+            nsamp = int(plies[fin].sum())
+            if self.device_samples:
+                import torch
+                dev = torch.device("cuda", e.device)
+                t = dict(states=torch.empty((nsamp, 4, e.N, e.N), dtype=torch.float32, device=dev),
+                         pi=torch.empty((nsamp, e.S), dtype=torch.float64, device=dev),
+                         z=torch.empty(nsamp, dtype=torch.float32, device=dev),
+                         game_id=torch.empty(nsamp, dtype=torch.int64, device=dev),
+                         ply=torch.empty(nsamp, dtype=torch.int32, device=dev))
+                k = e.drain_samples_device(t["states"], t["pi"], t["z"], t["game_id"], t["ply"])
+                out = {name: v[:k] for name, v in t.items()}
+            else:
+                out = e.drain_samples(max(1, nsamp))
+            if self.on_samples is not None:
+                self.on_samples(out)
+            self.games_done += nfin
+            self.plies_done += nsamp
+            self._assign(np.nonzero(fin)[0])
+        return nfin, nsamp
