@@ -35,6 +35,30 @@ class Config(C.Structure):
 _lib = None
 
 
+def _load_hip_runtime():
+    """Make exactly one HIP runtime visible before libazgomoku.so resolves its hip* symbols.
+
+    PyTorch-ROCm wheels bundle their own libamdhip64.so / libhsa-runtime64.so; a second
+    runtime from /opt/rocm in the same process would own separate device contexts (device
+    pointers of one are unknown to the other, and whichever initialises second may see no
+    GPU).  So: use PyTorch's copy when PyTorch is installed, else the system one."""
+    import importlib.util
+    candidates = []
+    spec = importlib.util.find_spec("torch")
+    if spec is not None and spec.origin:
+        candidates.append(os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so"))
+    candidates += ["/opt/rocm/lib/libamdhip64.so", "libamdhip64.so.7", "libamdhip64.so"]
+    errors = []
+    for c in candidates:
+        if os.path.isabs(c) and not os.path.exists(c):
+            continue
+        try:
+            return C.CDLL(c, mode=C.RTLD_GLOBAL)
+        except OSError as e:          # keep looking, report all at the end
+            errors.append("%s: %s" % (c, e))
+    raise ImportError("no HIP runtime (libamdhip64) could be loaded: " + "; ".join(errors))
+
+
 def load():
     """Load the shared library (raises if it was not built)."""
     global _lib
@@ -44,6 +68,7 @@ def load():
         raise ImportError(
             "libazgomoku.so not found at %s: build it with alphazero_gomoku_amd/csrc/build.sh "
             "(hipcc --offload-arch=gfx950); this package has no CPU fallback" % LIB_PATH)
+    _load_hip_runtime()
     L = C.CDLL(LIB_PATH)
     vp, i32p, f32p, f64p = C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_float), C.POINTER(C.c_double)
     u8p, i8p, u64p, i64p = C.POINTER(C.c_uint8), C.POINTER(C.c_int8), C.POINTER(C.c_uint64), C.POINTER(C.c_int64)

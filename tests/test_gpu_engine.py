@@ -254,3 +254,54 @@ def test_error_paths(az):
         eng.status()                                         # arena overflow is reported
     assert e.value.code == -4
     eng.close()
+
+
+def test_dropin_surface_reproduces_reference_games(az):
+    """Board / Game.start_self_play / MCTSPlayer.get_action with the reference's signatures:
+    np.random.seed(s) followed by start_self_play must give the reference's recorded game."""
+    games = [g for g in load("g3_games.npz")["games"] if g["cb"] in MODES and g["n"] in (6, 8)][:4]
+    for g in games:
+        n, k = int(g["n"]), int(g["k"])
+        board = az.Board(width=n, height=n, n_in_row=k)
+        game = az.Game(board)
+        player = az.MCTSPlayer(g["cb"], c_puct=float(g["c_puct"]), n_playout=int(g["n_playout"]), is_selfplay=1)
+        np.random.seed(int(g["seed"]))
+        winner, data = game.start_self_play(player, temp=float(g["temp"]))
+        data = list(data)
+        assert winner == g["winner"] and len(data) == len(g["moves"])
+        for t, (st, pi, z) in enumerate(data):
+            assert np.array_equal(st, g["states"][t].astype(np.float64))
+            np.testing.assert_allclose(pi, g["pi"][t], rtol=0, atol=1e-12)
+            assert z == g["z"][t]
+
+
+def test_policy_value_net_surface(az, oracle):
+    """PolicyValueNet.policy_value / policy_value_fn run the HIP CNN; MCTSPlayer accepts the
+    bound method as train.py passes it; start_self_play_batch returns per-game tuples."""
+    n, k = 6, 4
+    params = helpers.make_params(n, seed=106)
+    net = az.PolicyValueNet(n, n)
+    net.load_numpy_params(params)
+    board = az.Board(width=n, height=n, n_in_row=k)
+    board.init_board()
+    for m in (14, 15, 20):
+        board.do_move(m)
+    onet = oracle.OracleNet(n, n, params, precise=True)
+    po, vo = onet.forward(board.current_state())
+    ap, v = net.policy_value_fn(board)
+    ap = list(ap)
+    assert [a for a, _ in ap] == board.availables
+    assert max(abs(p - po[a]) for a, p in ap) < 1e-4 and abs(v - vo) < 1e-4
+    probs, vals = net.policy_value(np.stack([board.current_state()] * 3))
+    assert probs.shape == (3, n * n) and vals.shape == (3, 1)
+    player = az.MCTSPlayer(net.policy_value_fn, c_puct=5, n_playout=30, is_selfplay=1)
+    np.random.seed(3)
+    move, pi = player.get_action(board, temp=1.0, return_prob=1)
+    assert move in board.availables and abs(pi.sum() - 1.0) < 1e-9
+    loss, ent = net.train_step(np.stack([board.current_state()] * 4), np.stack([pi] * 4), np.ones(4), 2e-3)
+    assert np.isfinite(loss) and np.isfinite(ent)
+    out = az.Game(board).start_self_play_batch(net, n_games=5, n_playout=20, n_parallel=3, seed0=11)
+    assert sorted(gid for gid, _, _, _ in out) == [0, 1, 2, 3, 4]
+    for gid, states, mcts_probs, z in out:
+        assert states.shape[1:] == (4, n, n) and mcts_probs.shape == (len(z), n * n)
+        assert set(np.unique(z)).issubset({-1.0, 0.0, 1.0})
