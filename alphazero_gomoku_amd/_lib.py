@@ -8,6 +8,7 @@ LIB_PATH = os.path.join(_HERE, "libazgomoku.so")
 
 PRIOR_NET, PRIOR_UNIFORM32, PRIOR_HASH = 0, 1, 2
 LAYOUT_TORCH, LAYOUT_THEANO = 0, 1
+CNN_F16X3, CNN_F32 = 0, 1
 
 ERROR_NAMES = {-1: "AZG_EINVAL", -2: "AZG_EHIP", -3: "AZG_ENOWEIGHTS", -4: "AZG_EARENA",
                -5: "AZG_ESTATE", -6: "AZG_EMOVE"}
@@ -29,7 +30,7 @@ class AzgError(RuntimeError):
 class Config(C.Structure):
     _fields_ = [("board_n", C.c_int32), ("n_in_row", C.c_int32), ("n_playout", C.c_int32),
                 ("n_games", C.c_int32), ("c_puct", C.c_double), ("device", C.c_int32),
-                ("prior_mode", C.c_int32), ("arena_nodes", C.c_int32), ("reserved", C.c_int32)]
+                ("prior_mode", C.c_int32), ("arena_nodes", C.c_int32), ("cnn_mode", C.c_int32)]
 
 
 _lib = None

@@ -36,8 +36,10 @@ struct CnnGeom {
     static constexpr int END = WH_OFF + 6 * 128;
     // scratch that aliases IN + A1 once conv2 has consumed them
     static constexpr int HP_OFF = 0;                          // head partials [4 waves][6][NTP]
-    static constexpr int HF_OFF = HP_OFF + 24 * NTP;          // head outputs [T][6S]
-    static constexpr int LG_OFF = HF_OFF + T_ * 6 * S;        // logits -> probs [T][S]
+    static constexpr int VL = (2 * S + 3) & ~3;               // value-head features padded to 4
+    static constexpr int HFS = 4 * S + VL;                    // head outputs per position
+    static constexpr int HF_OFF = HP_OFF + 24 * NTP;          // head outputs [T][HFS]
+    static constexpr int LG_OFF = HF_OFF + T_ * HFS;          // logits -> probs [T][S]
     static constexpr int HD_OFF = LG_OFF + T_ * S;            // value hidden [T][64]
     static constexpr int VAL_OFF = HD_OFF + T_ * 64;          // values [T]
     static_assert(VAL_OFF + T_ <= A2_OFF, "scratch does not fit under IN+A1");
@@ -114,75 +116,14 @@ __device__ inline void conv3x3_tiles(const float *__restrict__ wp, const float *
     }
 }
 
-// Full forward.  `input(leaf, plane, row, col)` supplies the 0/1 feature planes
-// (game.py:92-116 layout).  Results: lds[LG_OFF + leaf*S + a] = probability of move a,
-// lds[VAL_OFF + leaf] = value.  Every thread of the 256-thread workgroup must call
-// this; it ends with a __syncthreads().  lds[A2_OFF..] halos must be zero on entry
-// (cnn_prepare) and lds[WH_OFF..] must hold the head weights.
-template <class G, class InputFn>
-__device__ inline void cnn_forward(const NetWeights &nw, float *lds, InputFn input)
+// Everything after conv3: sum the head partials of the four channel tiles, the fully
+// connected layers, softmax and tanh.  Shared by the f32 and the split-f16 convolution
+// front ends (G supplies the scratch offsets, in floats).
+template <class G>
+__device__ inline void cnn_tail(const NetWeights &nw, float *lds, Prof &prof)
 {
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
-    const int half = lane >> 5, j = lane & 31;
-
-    // ---- input planes with halo; A1 cleared (its halo must read as zero)
-    for (int idx = tid; idx < 4 * G::CS; idx += 256) {
-        const int ch = idx / G::CS, rem = idx - ch * G::CS;
-        const int leaf = rem / G::PS, q = rem - leaf * G::PS;
-        const int hr = q / G::PW, hc = q - hr * G::PW;
-        float v = 0.0f;
-        if (hr >= 1 && hr <= G::N && hc >= 1 && hc <= G::N) v = input(leaf, ch, hr - 1, hc - 1);
-        lds[G::IN_OFF + idx] = v;
-    }
-    for (int idx = tid; idx < 32 * G::CS; idx += 256) lds[G::A1_OFF + idx] = 0.0f;
-    __syncthreads();
-
-    // ---- conv1 4 -> 32, conv2 32 -> 64: ReLU, store with the halo offset
-    auto store_relu = [&](float *out) {
-        return [=](int, int tile, const f32x16 &acc, int posoff) {
-            const int cotile = 0;
-            (void)cotile;
-            if (tile * 32 + j < G::NP) {
-#pragma unroll
-                for (int r = 0; r < 16; r++) {
-                    const float v = acc[r] > 0.0f ? acc[r] : 0.0f;
-                    out[acc_row(r, half) * G::CS + posoff + G::PW + 1] = v;
-                }
-            }
-        };
-    };
-    conv3x3_tiles<G, 4, 32>(nw.wconv[0], nw.bconv[0], lds + G::IN_OFF, wave, lane,
-                            store_relu(lds + G::A1_OFF));
-    __syncthreads();
-    conv3x3_tiles<G, 32, 64>(nw.wconv[1], nw.bconv[1], lds + G::A1_OFF, wave, lane,
-                             store_relu(lds + G::A2_OFF + (wave % 2) * 32 * G::CS));
-    __syncthreads();
-
-    // ---- conv3 64 -> 128 with the 1x1 heads folded into the epilogue
-    {
-        const float *wh = lds + G::WH_OFF;
-        float *hp = lds + G::HP_OFF + wave * 6 * G::NTP;
-        conv3x3_tiles<G, 64, 128>(nw.wconv[2], nw.bconv[2], lds + G::A2_OFF, wave, lane,
-            [=](int, int tile, const f32x16 &acc, int) {
-                float s[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int r = 0; r < 16; r++) {
-                    const float v = acc[r] > 0.0f ? acc[r] : 0.0f;
-                    const int co = wave * 32 + acc_row(r, half);
-#pragma unroll
-                    for (int c = 0; c < 6; c++) s[c] = __builtin_fmaf(wh[c * 128 + co], v, s[c]);
-                }
-#pragma unroll
-                for (int c = 0; c < 6; c++) {
-                    const float o = __shfl_xor(s[c], 32);
-                    const float lo = half ? o : s[c], hi = half ? s[c] : o;
-                    if (!half) hp[c * G::NTP + tile * 32 + j] = lo + hi;
-                }
-            });
-    }
-    __syncthreads();
-
     // ---- head outputs: bias + the four channel-tile partials, ReLU, flattened [c][row][col]
     for (int idx = tid; idx < 6 * G::NP; idx += 256) {
         const int c = idx / G::NP, p = idx - c * G::NP;
@@ -191,28 +132,55 @@ __device__ inline void cnn_forward(const NetWeights &nw, float *lds, InputFn inp
         for (int w = 0; w < 4; w++) s += lds[G::HP_OFF + (w * 6 + c) * G::NTP + p];
         s = s > 0.0f ? s : 0.0f;
         const int leaf = p / G::S, cell = p - leaf * G::S;
-        lds[G::HF_OFF + leaf * 6 * G::S + c * G::S + cell] = s;
+        lds[G::HF_OFF + leaf * G::HFS + c * G::S + cell] = s;
+    }
+    if (G::VL > 2 * G::S && tid < G::T * (G::VL - 2 * G::S)) {       // zero the k padding of the value part
+        const int leaf = tid / (G::VL - 2 * G::S), e = tid - leaf * (G::VL - 2 * G::S);
+        lds[G::HF_OFF + leaf * G::HFS + 6 * G::S + e] = 0.0f;
     }
     __syncthreads();
+    prof.mark(7);
 
-    // ---- fully connected layers: policy logits (4S -> S) and value hidden (2S -> 64)
-    for (int item = tid; item < G::T * G::S + G::T * 64; item += 256) {
-        if (item < G::T * G::S) {
-            const int leaf = item / G::S, a = item - leaf * G::S;
-            const float *x = lds + G::HF_OFF + leaf * 6 * G::S;
-            float s = nw.bpfc[a];
-            for (int k = 0; k < 4 * G::S; k++) s = __builtin_fmaf(nw.wpfc[k * G::S + a], x[k], s);
-            lds[G::LG_OFF + item] = s;
-        } else {
-            const int q = item - G::T * G::S;
-            const int leaf = q >> 6, o = q & 63;
-            const float *x = lds + G::HF_OFF + leaf * 6 * G::S + 4 * G::S;
-            float s = nw.bvfc1[o];
-            for (int k = 0; k < 2 * G::S; k++) s = __builtin_fmaf(nw.wvfc1[k * 64 + o], x[k], s);
-            lds[G::HD_OFF + q] = s > 0.0f ? s : 0.0f;
+    // ---- fully connected layers: policy logits (4S -> S) and value hidden (2S -> 64).
+    //      One output per thread; the weights are packed [k/4][output][4] so a thread
+    //      reads 16 bytes per load and keeps 16 loads (64 weights) in flight.
+    {
+        auto dot = [&](const float4 *w4, int stride, const float4 *x4, int nkb, float bias) {
+            float s0 = bias, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+            for (int kb0 = 0; kb0 < nkb; kb0 += 16) {
+                float4 wv[16];
+#pragma unroll
+                for (int u = 0; u < 16; u++)
+                    wv[u] = (kb0 + u < nkb) ? w4[(size_t)(kb0 + u) * stride] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int u = 0; u < 16; u++) {
+                    if (kb0 + u < nkb) {
+                        const float4 xv = x4[kb0 + u];
+                        s0 = __builtin_fmaf(wv[u].x, xv.x, s0);
+                        s1 = __builtin_fmaf(wv[u].y, xv.y, s1);
+                        s2 = __builtin_fmaf(wv[u].z, xv.z, s2);
+                        s3 = __builtin_fmaf(wv[u].w, xv.w, s3);
+                    }
+                }
+            }
+            return (s0 + s1) + (s2 + s3);
+        };
+        for (int item = tid; item < G::T * G::S + G::T * 64; item += 256) {
+            if (item < G::T * G::S) {
+                const int leaf = item / G::S, o = item - leaf * G::S;
+                const float4 *x4 = reinterpret_cast<const float4 *>(lds + G::HF_OFF + leaf * G::HFS);
+                lds[G::LG_OFF + item] = dot(reinterpret_cast<const float4 *>(nw.wpfc) + o, G::S, x4, G::S, nw.bpfc[o]);
+            } else {
+                const int q = item - G::T * G::S;
+                const int leaf = q >> 6, o = q & 63;
+                const float4 *x4 = reinterpret_cast<const float4 *>(lds + G::HF_OFF + leaf * G::HFS + 4 * G::S);
+                const float s = dot(reinterpret_cast<const float4 *>(nw.wvfc1) + o, 64, x4, G::VL / 4, nw.bvfc1[o]);
+                lds[G::HD_OFF + q] = s > 0.0f ? s : 0.0f;
+            }
         }
     }
     __syncthreads();
+    prof.mark(8);
 
     // ---- softmax over the S logits and the scalar value, one wave per position
     if (wave < G::T) {
@@ -248,6 +216,85 @@ __device__ inline void cnn_forward(const NetWeights &nw, float *lds, InputFn inp
         if (lane == 0) lds[G::VAL_OFF + leaf] = tanhf(v + nw.bvfc2[0]);
     }
     __syncthreads();
+    prof.mark(9);
+}
+
+// Full forward.  `input(leaf, plane, row, col)` supplies the 0/1 feature planes
+// (game.py:92-116 layout).  Results: lds[LG_OFF + leaf*S + a] = probability of move a,
+// lds[VAL_OFF + leaf] = value.  Every thread of the 256-thread workgroup must call
+// this; it ends with a __syncthreads().  lds[A2_OFF..] halos must be zero on entry
+// (cnn_prepare) and lds[WH_OFF..] must hold the head weights.
+template <class G, class InputFn>
+__device__ inline void cnn_forward(const NetWeights &nw_in, float *lds, InputFn input, Prof &prof)
+{
+    const NetWeights nw = opaque_weights(nw_in);
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int half = lane >> 5, j = lane & 31;
+
+    // ---- input planes with halo; A1 cleared (its halo must read as zero)
+    for (int idx = tid; idx < 4 * G::CS; idx += 256) {
+        const int ch = idx / G::CS, rem = idx - ch * G::CS;
+        const int leaf = rem / G::PS, q = rem - leaf * G::PS;
+        const int hr = q / G::PW, hc = q - hr * G::PW;
+        float v = 0.0f;
+        if (hr >= 1 && hr <= G::N && hc >= 1 && hc <= G::N) v = input(leaf, ch, hr - 1, hc - 1);
+        lds[G::IN_OFF + idx] = v;
+    }
+    for (int idx = tid; idx < 32 * G::CS; idx += 256) lds[G::A1_OFF + idx] = 0.0f;
+    __syncthreads();
+    prof.mark(2);
+
+    // ---- conv1 4 -> 32, conv2 32 -> 64: ReLU, store with the halo offset
+    auto store_relu = [&](float *out) {
+        return [=](int, int tile, const f32x16 &acc, int posoff) {
+            const int cotile = 0;
+            (void)cotile;
+            if (tile * 32 + j < G::NP) {
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const float v = acc[r] > 0.0f ? acc[r] : 0.0f;
+                    out[acc_row(r, half) * G::CS + posoff + G::PW + 1] = v;
+                }
+            }
+        };
+    };
+    conv3x3_tiles<G, 4, 32>(nw.wconv[0], nw.bconv[0], lds + G::IN_OFF, wave, lane,
+                            store_relu(lds + G::A1_OFF));
+    __syncthreads();
+    prof.mark(3);
+    conv3x3_tiles<G, 32, 64>(nw.wconv[1], nw.bconv[1], lds + G::A1_OFF, wave, lane,
+                             store_relu(lds + G::A2_OFF + (wave % 2) * 32 * G::CS));
+    __syncthreads();
+    prof.mark(4);
+
+    // ---- conv3 64 -> 128 with the 1x1 heads folded into the epilogue
+    {
+        const float *wh = lds + G::WH_OFF;
+        float *hp = lds + G::HP_OFF + wave * 6 * G::NTP;
+        conv3x3_tiles<G, 64, 128>(nw.wconv[2], nw.bconv[2], lds + G::A2_OFF, wave, lane,
+            [=](int, int tile, const f32x16 &acc, int) {
+                float s[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const float v = acc[r] > 0.0f ? acc[r] : 0.0f;
+                    const int co = wave * 32 + acc_row(r, half);
+#pragma unroll
+                    for (int c = 0; c < 6; c++) s[c] = __builtin_fmaf(wh[c * 128 + co], v, s[c]);
+                }
+#pragma unroll
+                for (int c = 0; c < 6; c++) {
+                    const float o = __shfl_xor(s[c], 32);
+                    const float lo = half ? o : s[c], hi = half ? s[c] : o;
+                    if (!half) hp[c * G::NTP + tile * 32 + j] = lo + hi;
+                }
+            });
+    }
+    prof.mark(5);
+    __syncthreads();
+    prof.mark(6);
+
+    cnn_tail<G>(nw, lds, prof);
 }
 
 // One-time LDS set-up for a workgroup that will call cnn_forward: zero the A2 image

@@ -19,16 +19,50 @@ __host__ __device__ inline int meta_k(unsigned m) { return (int)(m >> 16); }
 // per MFMA A operand: wconv[l][(cotile*KS + kstep)*64 + lane] =
 // W[co = cotile*32 + (lane&31)][ci = 2*(kstep/9) + (lane>>5)][tap = kstep%9].
 struct NetWeights {
-    const float *wconv[3];   // packed conv1..conv3
+    const float *wconv[3];   // packed conv1..conv3 (float32 path)
+    const void *w16[3];      // packed conv1..conv3 as split halves (azg_cnn16.hpp)
     const float *bconv[3];   // biases [32],[64],[128]
     const float *whead;      // [6][128]: rows 0-3 act_conv1, rows 4-5 val_conv1
     const float *bhead;      // [6]
-    const float *wpfc;       // act_fc1 transposed: [4S][S]
+    const float *wpfc;       // act_fc1 as [k/4][S outputs][4]   (k = input feature)
     const float *bpfc;       // [S]
-    const float *wvfc1;      // val_fc1 transposed: [2S][64]
+    const float *wvfc1;      // val_fc1 as [k/4][64 outputs][4], k zero-padded to a multiple of 4
     const float *bvfc1;      // [64]
     const float *wvfc2;      // [64]
     const float *bvfc2;      // [1]
+};
+
+// Returns p unchanged but opaque to the optimiser.  The CNN runs inside the playout loop and
+// its weights never change during a launch; without this the compiler hoists weight loads
+// out of that loop and spills hundreds of registers to keep them.
+template <typename T>
+__device__ inline const T *opaque(const T *p)
+{
+    asm volatile("" : "+s"(p));
+    return p;
+}
+
+// A copy of the weight table whose pointers are opaque (call once per forward pass).
+__device__ inline NetWeights opaque_weights(const NetWeights &w)
+{
+    NetWeights o;
+    for (int i = 0; i < 3; i++) { o.wconv[i] = opaque(w.wconv[i]); o.w16[i] = opaque((const char *)w.w16[i]); o.bconv[i] = opaque(w.bconv[i]); }
+    o.whead = opaque(w.whead); o.bhead = opaque(w.bhead); o.wpfc = opaque(w.wpfc); o.bpfc = opaque(w.bpfc);
+    o.wvfc1 = opaque(w.wvfc1); o.bvfc1 = opaque(w.bvfc1); o.wvfc2 = opaque(w.wvfc2); o.bvfc2 = opaque(w.bvfc2);
+    return o;
+}
+
+// Phase timer of the diagnostic build: thread 0 of workgroup 0 adds the cycles since its
+// previous mark to slot i.  Compiles to nothing in the normal build.
+struct Prof {
+#ifdef AZG_STAMPS
+    long long *out; long long last; bool on;
+    __device__ void start(long long *o) { out = o; on = o != nullptr && blockIdx.x == 0 && threadIdx.x == 0; last = __builtin_amdgcn_s_memtime(); }
+    __device__ void mark(int i) { if (on) { const long long now = __builtin_amdgcn_s_memtime(); out[i] += now - last; last = now; } }
+#else
+    __device__ void start(long long *) {}
+    __device__ void mark(int) {}
+#endif
 };
 
 // Everything the kernels need, passed by value.
@@ -60,6 +94,7 @@ struct DevState {
     int *s_count;                  // [B] samples recorded (= plies played by the engine)
     long long *game_id;            // [B]
     unsigned char *drained;        // [B]
+    long long *stamps;             // [32] cycle counters of a diagnostic build (-DAZG_STAMPS)
     NetWeights net;
 };
 

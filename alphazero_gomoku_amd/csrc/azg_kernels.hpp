@@ -2,7 +2,9 @@
 // work; the search kernel keeps T games per 256-thread workgroup and runs a whole
 // move's n_playout playouts in one launch with no inter-workgroup communication.
 #pragma once
-#include "azg_cnn.hpp"
+#include <type_traits>
+
+#include "azg_cnn16.hpp"
 #include "azg_tree.hpp"
 
 namespace azg {
@@ -13,11 +15,29 @@ __device__ inline void wg_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wo
 
 // ---------------------------------------------------------------- search
 // MCTS.get_move_probs' playout loop (mcts_alphaZero.py:161-163) for T games.
-// MODE: AZG_PRIOR_NET (0), UNIFORM32 (1), HASH (2).
-template <int N, int T, int MODE>
+// MODE: AZG_PRIOR_NET (0), UNIFORM32 (1), HASH (2).  F16: CNN on split-f16 operands
+// (azg_cnn16.hpp) instead of float32 MFMA (azg_cnn.hpp).
+template <int N, int T, bool F16>
+struct GeomPick { using type = typename std::conditional<F16, Cnn16Geom<N, T>, CnnGeom<N, T>>::type; };
+
+template <class G, bool F16, class InputFn>
+__device__ inline void net_forward(const NetWeights &nw, float *smem, InputFn input, Prof &prof)
+{
+    if constexpr (F16) cnn16_forward<G>(nw, smem, input, prof);
+    else cnn_forward<G>(nw, smem, input, prof);
+}
+
+template <class G, bool F16>
+__device__ inline void net_prepare(const NetWeights &nw, float *smem)
+{
+    if constexpr (F16) cnn16_prepare<G>(nw, smem);
+    else cnn_prepare<G>(nw, smem);
+}
+
+template <int N, int T, int MODE, bool F16>
 __global__ __launch_bounds__(256) void search_kernel(DevState st)
 {
-    using G = CnnGeom<(MODE == 0 ? N : 4), (MODE == 0 ? T : 1)>;
+    using G = typename GeomPick<(MODE == 0 ? N : 4), (MODE == 0 ? T : 1), F16>::type;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     GameLds *gls = reinterpret_cast<GameLds *>(smem + (MODE == 0 ? G::END : 0));
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -45,13 +65,15 @@ __global__ __launch_bounds__(256) void search_kernel(DevState st)
 #pragma unroll
     for (int t = 0; t < T; t++) any_live |= gls[t].live != 0;
     if (!any_live) return;
-    if (MODE == 0) cnn_prepare<G>(st.net, smem);
+    if (MODE == 0) net_prepare<G, F16>(st.net, smem);
 
     const bool active = tree_wave && gl->live;
     TreeView tv;
     int first_player = 1;
     if (active) { tv = tree_view(st, g, st.cur[g]); first_player = gl->first_player; }
     long long n_eval = 0;
+    Prof prof;
+    prof.start(st.stamps);
 
     for (int it = 0; it < st.n_playout; it++) {
         Descent d = {0, 0, 0, 0};
@@ -62,18 +84,20 @@ __global__ __launch_bounds__(256) void search_kernel(DevState st)
             if (lane == 0) { gl->term = term; gl->need_eval = term == 0; }
             n_eval += term == 0;
         }
+        prof.mark(0);
         if (MODE == 0) {
             __syncthreads();
+            prof.mark(1);
             bool any = false;
 #pragma unroll
             for (int t = 0; t < T; t++) any |= gls[t].live && gls[t].need_eval;
             if (any) {
-                cnn_forward<G>(st.net, smem, [&](int leaf, int pl, int row, int col) -> float {
+                net_forward<G, F16>(st.net, smem, [&](int leaf, int pl, int row, int col) -> float {
                     const GameLds *q = &gls[leaf];
                     if (!q->live) return 0.0f;
                     return plane_value(q->leaf_bb, N, q->leaf_ply, q->leaf_last,
                                        player_at(q->first_player, q->leaf_ply), pl, row, col);
-                });
+                }, prof);
             } else {
                 __syncthreads();
             }
@@ -100,24 +124,27 @@ __global__ __launch_bounds__(256) void search_kernel(DevState st)
             wave_backup(tv, gl, d.depth, v, lane);
             wg_fence();
         }
+        prof.mark(10);
     }
     if (active && lane == 0) st.evals[g] += n_eval;
 }
 
 // ---------------------------------------------------------------- eval_batch
 // PolicyValueNet.policy_value (policy_value_net_pytorch.py:80-94) on n states.
-template <int N, int T>
+template <int N, int T, bool F16>
 __global__ __launch_bounds__(256) void eval_kernel(NetWeights nw, const float *states, int n,
                                                    float *probs, float *values)
 {
-    using G = CnnGeom<N, T>;
+    using G = typename GeomPick<N, T, F16>::type;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int n0 = blockIdx.x * T;
-    cnn_prepare<G>(nw, smem);
-    cnn_forward<G>(nw, smem, [&](int leaf, int pl, int row, int col) -> float {
+    net_prepare<G, F16>(nw, smem);
+    Prof prof;
+    prof.start(nullptr);
+    net_forward<G, F16>(nw, smem, [&](int leaf, int pl, int row, int col) -> float {
         const int i = n0 + leaf;
         return i < n ? states[((size_t)i * 4 + pl) * G::S + row * N + col] : 0.0f;
-    });
+    }, prof);
     for (int idx = threadIdx.x; idx < T * G::S; idx += 256) {
         const int leaf = idx / G::S;
         if (n0 + leaf < n) probs[(size_t)n0 * G::S + idx] = smem[G::LG_OFF + idx];

@@ -99,21 +99,22 @@ struct SearchLaunch {
     size_t lds;
 };
 
-template <int N, int T>
+template <int N, int T, bool F16>
 static SearchLaunch net_launch()
 {
-    using G = CnnGeom<N, T>;
-    return {search_kernel<N, T, 0>, T, (size_t)G::END * 4 + T * sizeof(GameLds)};
+    using G = typename GeomPick<N, T, F16>::type;
+    return {search_kernel<N, T, 0, F16>, T, (size_t)G::END * 4 + T * sizeof(GameLds)};
 }
 
-static bool pick_search(int N, int mode, SearchLaunch *out)
+static bool pick_search(int N, int mode, int cnn_mode, SearchLaunch *out)
 {
-    if (mode == AZG_PRIOR_UNIFORM32) { *out = {search_kernel<0, 4, 1>, 4, 4 * sizeof(GameLds)}; return true; }
-    if (mode == AZG_PRIOR_HASH) { *out = {search_kernel<0, 4, 2>, 4, 4 * sizeof(GameLds)}; return true; }
+    if (mode == AZG_PRIOR_UNIFORM32) { *out = {search_kernel<0, 4, 1, false>, 4, 4 * sizeof(GameLds)}; return true; }
+    if (mode == AZG_PRIOR_HASH) { *out = {search_kernel<0, 4, 2, false>, 4, 4 * sizeof(GameLds)}; return true; }
+    const bool f16 = cnn_mode == AZG_CNN_F16X3;
     switch (N) {
-    case 6: *out = net_launch<6, 2>(); return true;
-    case 8: *out = net_launch<8, 2>(); return true;
-    case 15: *out = net_launch<15, 1>(); return true;
+    case 6: *out = f16 ? net_launch<6, 2, true>() : net_launch<6, 2, false>(); return true;
+    case 8: *out = f16 ? net_launch<8, 2, true>() : net_launch<8, 2, false>(); return true;
+    case 15: *out = f16 ? net_launch<15, 1, true>() : net_launch<15, 1, false>(); return true;
     default: return false;
     }
 }
@@ -124,19 +125,20 @@ struct EvalLaunch {
     size_t lds;
 };
 
-template <int N, int T>
+template <int N, int T, bool F16>
 static EvalLaunch eval_launch()
 {
-    using G = CnnGeom<N, T>;
-    return {eval_kernel<N, T>, T, (size_t)G::END * 4};
+    using G = typename GeomPick<N, T, F16>::type;
+    return {eval_kernel<N, T, F16>, T, (size_t)G::END * 4};
 }
 
-static bool pick_eval(int N, EvalLaunch *out)
+static bool pick_eval(int N, int cnn_mode, EvalLaunch *out)
 {
+    const bool f16 = cnn_mode == AZG_CNN_F16X3;
     switch (N) {
-    case 6: *out = eval_launch<6, 2>(); return true;
-    case 8: *out = eval_launch<8, 2>(); return true;
-    case 15: *out = eval_launch<15, 1>(); return true;
+    case 6: *out = f16 ? eval_launch<6, 2, true>() : eval_launch<6, 2, false>(); return true;
+    case 8: *out = f16 ? eval_launch<8, 2, true>() : eval_launch<8, 2, false>(); return true;
+    case 15: *out = f16 ? eval_launch<15, 1, true>() : eval_launch<15, 1, false>(); return true;
     default: return false;
     }
 }
@@ -234,6 +236,7 @@ static int create_impl(azg_handle *h)
     if ((rc = dev_alloc(h, &st.s_count, B))) return rc;
     if ((rc = dev_alloc(h, &st.game_id, B))) return rc;
     if ((rc = dev_alloc(h, &st.drained, B))) return rc;
+    if ((rc = dev_alloc(h, &st.stamps, 32))) return rc;
     if ((rc = dev_alloc(h, &h->d_noise, (size_t)B * S))) return rc;
     if ((rc = dev_alloc(h, &h->d_u, B))) return rc;
     if ((rc = dev_alloc(h, &h->d_pi, (size_t)B * S))) return rc;
@@ -252,10 +255,10 @@ static int create_impl(azg_handle *h)
     HIPCHK(h, hipMemsetAsync(st.drained, 1, B, h->stream));
     // opt in to the large dynamic LDS of the CNN kernels
     SearchLaunch sl;
-    if (pick_search(N, c.prior_mode, &sl))
+    if (pick_search(N, c.prior_mode, c.cnn_mode, &sl))
         HIPCHK(h, hipFuncSetAttribute((const void *)sl.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sl.lds));
     EvalLaunch el;
-    if (pick_eval(N, &el))
+    if (pick_eval(N, c.cnn_mode, &el))
         HIPCHK(h, hipFuncSetAttribute((const void *)el.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)el.lds));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return AZG_OK;
@@ -272,7 +275,8 @@ extern "C" int azg_create(const azg_config *cfg, azg_handle **out)
     if (cfg->n_playout < 1) return fail(nullptr, AZG_EINVAL, "n_playout must be positive");
     if (cfg->prior_mode < 0 || cfg->prior_mode > 2) return fail(nullptr, AZG_EINVAL, "bad prior_mode %d", cfg->prior_mode);
     SearchLaunch sl;
-    if (!pick_search(cfg->board_n, cfg->prior_mode, &sl))
+    if (cfg->cnn_mode != AZG_CNN_F16X3 && cfg->cnn_mode != AZG_CNN_F32) return fail(nullptr, AZG_EINVAL, "bad cnn_mode %d", cfg->cnn_mode);
+    if (!pick_search(cfg->board_n, cfg->prior_mode, cfg->cnn_mode, &sl))
         return fail(nullptr, AZG_EINVAL, "no CNN search kernel is built for board_n=%d (built: 6, 8, 15)", cfg->board_n);
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(nullptr, AZG_EHIP, "no HIP device available");
@@ -301,6 +305,27 @@ static void pack_conv(const float *w, int cin, int cout, float *out)
             for (int lane = 0; lane < 64; lane++) {
                 const int co = cot * 32 + (lane & 31), ci = 2 * (ks / 9) + (lane >> 5), tap = ks % 9;
                 out[((size_t)cot * KS + ks) * 64 + lane] = w[((size_t)co * cin + ci) * 9 + tap];
+            }
+}
+
+// Split-f16 image of a conv kernel for azg_cnn16.hpp: per (cotile, kstep = tap*CG + cg) and
+// lane, 8 high halves then 8 low halves of W[co][ci = cg*16 + 8*(lane>>5) + j][tap] * 2^8.
+static void pack_conv16(const float *w, int cin, int cinp, int cout, _Float16 *out)
+{
+    const int CG = cinp / 16, KS = 9 * CG;
+    for (int cot = 0; cot < cout / 32; cot++)
+        for (int ks = 0; ks < KS; ks++)
+            for (int lane = 0; lane < 64; lane++) {
+                const int tap = ks / CG, cg = ks % CG;
+                const int co = cot * 32 + (lane & 31);
+                _Float16 *dst = out + (((size_t)cot * KS + ks) * 64 + lane) * 16;
+                for (int j = 0; j < 8; j++) {
+                    const int ci = cg * 16 + 8 * (lane >> 5) + j;
+                    const float v = ci < cin ? w[((size_t)co * cin + ci) * 9 + tap] * kWScale : 0.0f;
+                    const _Float16 hi = (_Float16)v;
+                    dst[j] = hi;
+                    dst[8 + j] = (_Float16)(v - (float)hi);
+                }
             }
 }
 
@@ -338,13 +363,20 @@ extern "C" int azg_set_weights(azg_handle *h, const float *const ptrs[16], int l
     // engine layout
     auto al = [](size_t n) { return (n + 63) / 64 * 64; };
     size_t off[16], total = 0;
+    size_t off16[3];
     const size_t psz[14] = {(size_t)1 * 18 * 64, (size_t)2 * 144 * 64, (size_t)4 * 288 * 64, 32, 64, 128,
-                            6 * 128, 6, (size_t)4 * S * S, (size_t)S, (size_t)2 * S * 64, 64, 64, 1};
+                            6 * 128, 6, (size_t)4 * S * S, (size_t)S, (size_t)((2 * S + 3) / 4) * 64 * 4, 64, 64, 1};
     for (int i = 0; i < 14; i++) { off[i] = total; total += al(psz[i]); }
+    // split-f16 conv images: (cotiles * 9*CG k-steps * 64 lanes * 16 halves) / 2 floats
+    const size_t psz16[3] = {(size_t)1 * 9 * 64 * 8, (size_t)2 * 18 * 64 * 8, (size_t)4 * 36 * 64 * 8};
+    for (int i = 0; i < 3; i++) { off16[i] = total; total += al(psz16[i]); }
     std::vector<float> host(total, 0.f);
     pack_conv(t[0].data(), 4, 32, &host[off[0]]);
     pack_conv(t[2].data(), 32, 64, &host[off[1]]);
     pack_conv(t[4].data(), 64, 128, &host[off[2]]);
+    pack_conv16(t[0].data(), 4, 16, 32, reinterpret_cast<_Float16 *>(&host[off16[0]]));
+    pack_conv16(t[2].data(), 32, 32, 64, reinterpret_cast<_Float16 *>(&host[off16[1]]));
+    pack_conv16(t[4].data(), 64, 64, 128, reinterpret_cast<_Float16 *>(&host[off16[2]]));
     std::copy(t[1].begin(), t[1].end(), &host[off[3]]);
     std::copy(t[3].begin(), t[3].end(), &host[off[4]]);
     std::copy(t[5].begin(), t[5].end(), &host[off[5]]);
@@ -353,10 +385,10 @@ extern "C" int azg_set_weights(azg_handle *h, const float *const ptrs[16], int l
     std::copy(t[7].begin(), t[7].end(), &host[off[7]]);
     std::copy(t[11].begin(), t[11].end(), &host[off[7] + 4]);
     for (int a = 0; a < S; a++)
-        for (int k = 0; k < 4 * S; k++) host[off[8] + (size_t)k * S + a] = t[8][(size_t)a * 4 * S + k];
+        for (int k = 0; k < 4 * S; k++) host[off[8] + ((size_t)(k / 4) * S + a) * 4 + k % 4] = t[8][(size_t)a * 4 * S + k];
     std::copy(t[9].begin(), t[9].end(), &host[off[9]]);
     for (int o = 0; o < 64; o++)
-        for (int k = 0; k < 2 * S; k++) host[off[10] + (size_t)k * 64 + o] = t[12][(size_t)o * 2 * S + k];
+        for (int k = 0; k < 2 * S; k++) host[off[10] + ((size_t)(k / 4) * 64 + o) * 4 + k % 4] = t[12][(size_t)o * 2 * S + k];
     std::copy(t[13].begin(), t[13].end(), &host[off[11]]);
     std::copy(t[14].begin(), t[14].end(), &host[off[12]]);
     host[off[13]] = t[15][0];
@@ -366,6 +398,7 @@ extern "C" int azg_set_weights(azg_handle *h, const float *const ptrs[16], int l
     NetWeights &nw = h->st.net;
     const float *d = h->d_weights;
     nw.wconv[0] = d + off[0]; nw.wconv[1] = d + off[1]; nw.wconv[2] = d + off[2];
+    nw.w16[0] = d + off16[0]; nw.w16[1] = d + off16[1]; nw.w16[2] = d + off16[2];
     nw.bconv[0] = d + off[3]; nw.bconv[1] = d + off[4]; nw.bconv[2] = d + off[5];
     nw.whead = d + off[6]; nw.bhead = d + off[7];
     nw.wpfc = d + off[8]; nw.bpfc = d + off[9];
@@ -434,7 +467,7 @@ extern "C" int azg_search(azg_handle *h)
     if (h->cfg.prior_mode == AZG_PRIOR_NET && !h->have_weights)
         return fail(h, AZG_ENOWEIGHTS, "azg_set_weights must be called before a net-driven search");
     SearchLaunch sl;
-    if (!pick_search(h->cfg.board_n, h->cfg.prior_mode, &sl)) return fail(h, AZG_EINVAL, "no search kernel");
+    if (!pick_search(h->cfg.board_n, h->cfg.prior_mode, h->cfg.cnn_mode, &sl)) return fail(h, AZG_EINVAL, "no search kernel");
     const int grid = (h->cfg.n_games + sl.T - 1) / sl.T;
     if (h->ev_pending == h->ev_pool.size()) {
         hipEvent_t a, b;
@@ -621,7 +654,7 @@ extern "C" int azg_eval_batch(azg_handle *h, const float *states, int n, float *
     if (n == 0) return AZG_OK;
     HIPCHK(h, hipSetDevice(h->cfg.device));
     EvalLaunch el;
-    if (!pick_eval(h->cfg.board_n, &el)) return fail(h, AZG_EINVAL, "no CNN kernel is built for board_n=%d", h->cfg.board_n);
+    if (!pick_eval(h->cfg.board_n, h->cfg.cnn_mode, &el)) return fail(h, AZG_EINVAL, "no CNN kernel is built for board_n=%d", h->cfg.board_n);
     const int S = h->st.S;
     void *ds, *dp, *dv;
     int rc;
@@ -677,6 +710,17 @@ extern "C" int azg_board_step_batch(azg_handle *h, int n, uint64_t *stones, int3
     if (planes) HIPCHK(h, hipMemcpyAsync(planes, d_planes, (size_t)n * 4 * S * 4, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     if (bad) return fail(h, AZG_EMOVE, "illegal move in batch (occupied cell, out of range, or bad player)");
+    return AZG_OK;
+}
+
+// Diagnostic builds (-DAZG_STAMPS) only: cycle counters of workgroup 0's phases.
+extern "C" int azg_debug_stamps(azg_handle *h, long long out[32])
+{
+    if (!h || !out) return AZG_EINVAL;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipMemcpy(out, h->st.stamps, 32 * sizeof(long long), hipMemcpyDeviceToHost));
+    HIPCHK(h, hipMemset(h->st.stamps, 0, 32 * sizeof(long long)));
     return AZG_OK;
 }
 

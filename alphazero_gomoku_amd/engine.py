@@ -18,13 +18,13 @@ class SelfPlayEngine:
     and Game.start_self_play (game.py:360-416) of the reference."""
 
     def __init__(self, board_n=8, n_in_row=5, n_playout=400, n_games=1, c_puct=5.0, device=0,
-                 prior_mode=PRIOR_NET, arena_nodes=0):
+                 prior_mode=PRIOR_NET, arena_nodes=0, cnn_mode=_lib.CNN_F16X3):
         self.L = _lib.load()
         self.N, self.S, self.B = int(board_n), int(board_n) ** 2, int(n_games)
         self.n_in_row, self.n_playout, self.c_puct = int(n_in_row), int(n_playout), float(c_puct)
         self.device, self.prior_mode = int(device), int(prior_mode)
         cfg = _lib.Config(self.N, self.n_in_row, self.n_playout, self.B, self.c_puct, self.device,
-                          self.prior_mode, int(arena_nodes), 0)
+                          self.prior_mode, int(arena_nodes), int(cnn_mode))
         h = C.c_void_p()
         rc = self.L.azg_create(C.byref(cfg), C.byref(h))
         if rc != 0:

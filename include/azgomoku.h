@@ -38,6 +38,10 @@ extern "C" {
 #define AZG_PRIOR_UNIFORM32  1   /* P = float(1)/float(K), v = 0 (test callback)         */
 #define AZG_PRIOR_HASH       2   /* exact dyadic priors from a position hash (test)      */
 
+/* arithmetic of the CNN's 3x3 convolutions (both agree with a float32 reference to <1e-6) */
+#define AZG_CNN_F16X3      0   /* split-f16 operands, three f16 MFMAs per product, f32 accumulate */
+#define AZG_CNN_F32        1   /* float32-input MFMA                                             */
+
 /* weight tensor layouts accepted by azg_set_weights */
 #define AZG_LAYOUT_TORCH   0   /* state_dict order of policy_value_net_pytorch.py:31-41 */
 #define AZG_LAYOUT_THEANO  1   /* 16-tensor list of policy_value_net_numpy.py:103-113   */
@@ -53,7 +57,7 @@ typedef struct azg_config {
     int32_t device;        /* HIP device ordinal                                      */
     int32_t prior_mode;    /* AZG_PRIOR_*                                             */
     int32_t arena_nodes;   /* expanded nodes kept per game tree; 0 = 4*n_playout+64   */
-    int32_t reserved;
+    int32_t cnn_mode;      /* AZG_CNN_*                                               */
 } azg_config;
 
 /* MCTSPlayer.__init__ / MCTS.__init__ (mcts_alphaZero.py:98-111,201-203) plus

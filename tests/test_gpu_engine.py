@@ -136,28 +136,30 @@ def test_seeded_games_match_reference(az):
         eng.close()
 
 
-def test_cnn_against_reference_and_oracle(az, oracle):
-    """azg_eval_batch (HIP CNN, float32 MFMA) against the reference's PyTorch and numpy
-    nets (golden) and the CPU oracle: |dp| and |dv| below 1e-4."""
+@pytest.mark.parametrize("cnn_mode", [0, 1], ids=["f16x3", "f32"])
+def test_cnn_against_reference_and_oracle(az, oracle, cnn_mode):
+    """azg_eval_batch (HIP CNN; split-f16 MFMA and float32 MFMA variants) against the
+    reference's PyTorch and numpy nets (golden) and the CPU oracle: |dp| and |dv| below the
+    1e-4 the north star allows; in practice both variants sit below 2e-6."""
     d = load("g4_cnn.npz")
     for (n, k, count, scale, seed) in d["spec"]:
         n, k, count, seed = int(n), int(k), int(count), int(seed)
         tag = "%d_s%g" % (n, scale)
         params = helpers.make_params(n, seed=seed, scale=float(scale))
-        eng = az.SelfPlayEngine(n, k, 1, 1)
+        eng = az.SelfPlayEngine(n, k, 1, 1, cnn_mode=cnn_mode)
         eng.set_weights(params)
         states = d["states_" + tag].astype(np.float32)
         probs, vals = eng.eval_batch(states)
         assert np.abs(probs - d["probs_torch_" + tag]).max() < 1e-4, tag
         assert np.abs(vals - d["value_torch_" + tag]).max() < 1e-4, tag
-        assert np.abs(probs - d["probs_numpy_" + tag]).max() < 1e-4, tag
-        assert np.abs(vals - d["value_numpy_" + tag]).max() < 1e-4, tag
+        assert np.abs(probs - d["probs_numpy_" + tag]).max() < 1e-5, tag
+        assert np.abs(vals - d["value_numpy_" + tag]).max() < 1e-5, tag
         net = oracle.OracleNet(n, n, params, precise=True)
         for i in range(0, count, 7):
             po, vo = net.forward(states[i].astype(np.float64))
-            assert np.abs(probs[i] - po).max() < 1e-4 and abs(vals[i] - vo) < 1e-4
+            assert np.abs(probs[i] - po).max() < 1e-5 and abs(vals[i] - vo) < 1e-5
         # the theano-layout entry point must give the same numbers
-        eng2 = az.SelfPlayEngine(n, k, 1, 1)
+        eng2 = az.SelfPlayEngine(n, k, 1, 1, cnn_mode=cnn_mode)
         eng2.set_weights(helpers.torch_to_theano_layout(params), layout=az._lib.LAYOUT_THEANO)
         p2, v2 = eng2.eval_batch(states)
         assert np.array_equal(p2, probs) and np.array_equal(v2, vals)
@@ -168,14 +170,16 @@ def test_cnn_against_reference_and_oracle(az, oracle):
         eng2.close()
 
 
-def test_net_search_bit_exact_vs_oracle_with_gpu_priors(az, oracle):
+@pytest.mark.parametrize("cnn_mode", [0, 1], ids=["f16x3", "f32"])
+def test_net_search_bit_exact_vs_oracle_with_gpu_priors(az, oracle, cnn_mode):
     """Net-driven search: the CPU oracle's MCTS, fed the GPU CNN's own float32 outputs
     through a callback, must reproduce the engine's visit counts bit-exactly."""
-    for (n, k, npo, prefix) in [(6, 4, 120, []), (8, 5, 200, []), (8, 5, 150, [27, 28, 35, 36, 20, 21])]:
+    for (n, k, npo, prefix) in [(6, 4, 120, []), (8, 5, 200, []), (8, 5, 150, [27, 28, 35, 36, 20, 21]),
+                                (15, 5, 60, [112, 113, 97])]:
         params = helpers.make_params(n, seed=100 + n, scale=2.0)
-        eng = az.SelfPlayEngine(n, k, npo, 1)
+        eng = az.SelfPlayEngine(n, k, npo, 1, cnn_mode=cnn_mode)
         eng.set_weights(params)
-        ev = az.SelfPlayEngine(n, k, 1, 1)
+        ev = az.SelfPlayEngine(n, k, 1, 1, cnn_mode=cnn_mode)
         ev.set_weights(params)
         eng.reset_games()
         st = stones_of(prefix)
