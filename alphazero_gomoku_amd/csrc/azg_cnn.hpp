@@ -19,6 +19,7 @@
 namespace azg {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 template <int N_, int T_>
 struct CnnGeom {
@@ -87,7 +88,7 @@ __device__ inline void conv3x3_tiles(const float *__restrict__ wp, const float *
         for (int i = 0; i < PT; i++) acc[i][r] = b;
     }
 
-    const float *wrow = wp + (size_t)cot * KS * 64 + lane;
+    const gptr<float> wrow = as_global(wp + (size_t)cot * KS * 64 + lane);
     float a_cur[9], a_nxt[9];
 #pragma unroll
     for (int t = 0; t < 9; t++) a_cur[t] = wrow[t * 64];
@@ -145,21 +146,23 @@ __device__ inline void cnn_tail(const NetWeights &nw, float *lds, Prof &prof)
     //      One output per thread; the weights are packed [k/4][output][4] so a thread
     //      reads 16 bytes per load and keeps 16 loads (64 weights) in flight.
     {
-        auto dot = [&](const float4 *w4, int stride, const float4 *x4, int nkb, float bias) {
+        auto dot = [&](gptr<f32x4> w4, int stride, const f32x4 *x4, int nkb, float bias) {
             float s0 = bias, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
             for (int kb0 = 0; kb0 < nkb; kb0 += 16) {
-                float4 wv[16];
+                f32x4 wv[16];
 #pragma unroll
-                for (int u = 0; u < 16; u++)
-                    wv[u] = (kb0 + u < nkb) ? w4[(size_t)(kb0 + u) * stride] : make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int u = 0; u < 16; u++) {
+                    const int kb = kb0 + u < nkb ? kb0 + u : nkb - 1;      // clamp: keeps the load unconditional
+                    wv[u] = w4[(size_t)kb * stride];
+                }
 #pragma unroll
                 for (int u = 0; u < 16; u++) {
                     if (kb0 + u < nkb) {
-                        const float4 xv = x4[kb0 + u];
-                        s0 = __builtin_fmaf(wv[u].x, xv.x, s0);
-                        s1 = __builtin_fmaf(wv[u].y, xv.y, s1);
-                        s2 = __builtin_fmaf(wv[u].z, xv.z, s2);
-                        s3 = __builtin_fmaf(wv[u].w, xv.w, s3);
+                        const f32x4 xv = x4[kb0 + u];
+                        s0 = __builtin_fmaf(wv[u][0], xv[0], s0);
+                        s1 = __builtin_fmaf(wv[u][1], xv[1], s1);
+                        s2 = __builtin_fmaf(wv[u][2], xv[2], s2);
+                        s3 = __builtin_fmaf(wv[u][3], xv[3], s3);
                     }
                 }
             }
@@ -168,13 +171,13 @@ __device__ inline void cnn_tail(const NetWeights &nw, float *lds, Prof &prof)
         for (int item = tid; item < G::T * G::S + G::T * 64; item += 256) {
             if (item < G::T * G::S) {
                 const int leaf = item / G::S, o = item - leaf * G::S;
-                const float4 *x4 = reinterpret_cast<const float4 *>(lds + G::HF_OFF + leaf * G::HFS);
-                lds[G::LG_OFF + item] = dot(reinterpret_cast<const float4 *>(nw.wpfc) + o, G::S, x4, G::S, nw.bpfc[o]);
+                const f32x4 *x4 = reinterpret_cast<const f32x4 *>(lds + G::HF_OFF + leaf * G::HFS);
+                lds[G::LG_OFF + item] = dot(as_global(reinterpret_cast<const f32x4 *>(nw.wpfc) + o), G::S, x4, G::S, nw.bpfc[o]);
             } else {
                 const int q = item - G::T * G::S;
                 const int leaf = q >> 6, o = q & 63;
-                const float4 *x4 = reinterpret_cast<const float4 *>(lds + G::HF_OFF + leaf * G::HFS + 4 * G::S);
-                const float s = dot(reinterpret_cast<const float4 *>(nw.wvfc1) + o, 64, x4, G::VL / 4, nw.bvfc1[o]);
+                const f32x4 *x4 = reinterpret_cast<const f32x4 *>(lds + G::HF_OFF + leaf * G::HFS + 4 * G::S);
+                const float s = dot(as_global(reinterpret_cast<const f32x4 *>(nw.wvfc1) + o), 64, x4, G::VL / 4, nw.bvfc1[o]);
                 lds[G::HD_OFF + q] = s > 0.0f ? s : 0.0f;
             }
         }

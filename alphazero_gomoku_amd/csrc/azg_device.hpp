@@ -42,6 +42,13 @@ __device__ inline const T *opaque(const T *p)
     return p;
 }
 
+// Global-memory view of a pointer.  After opaque() the compiler no longer knows the address
+// space and would emit flat loads, which count on both memory counters and force full waits.
+template <typename T>
+using gptr = const T __attribute__((address_space(1))) *;
+template <typename T>
+__device__ inline gptr<T> as_global(const T *p) { return (gptr<T>)p; }
+
 // A copy of the weight table whose pointers are opaque (call once per forward pass).
 __device__ inline NetWeights opaque_weights(const NetWeights &w)
 {

@@ -34,8 +34,10 @@ __device__ inline void net_prepare(const NetWeights &nw, float *smem)
     else cnn_prepare<G>(nw, smem);
 }
 
+// The split-f16 kernels for boards up to 8x8 need < 80 KB of LDS; two waves per SIMD (second
+// launch-bound argument) lets two workgroups share a CU.
 template <int N, int T, int MODE, bool F16>
-__global__ __launch_bounds__(256) void search_kernel(DevState st)
+__global__ __launch_bounds__(256, (F16 && MODE == 0 && N <= 8) ? 2 : 1) void search_kernel(DevState st)
 {
     using G = typename GeomPick<(MODE == 0 ? N : 4), (MODE == 0 ? T : 1), F16>::type;
     extern __shared__ __attribute__((aligned(16))) float smem[];
