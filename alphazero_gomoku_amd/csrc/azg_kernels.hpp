@@ -70,9 +70,8 @@ __global__ __launch_bounds__(256, (F16 && MODE == 0 && N <= 8) ? 2 : 1) void sea
     if (MODE == 0) net_prepare<G, F16>(st.net, smem);
 
     const bool active = tree_wave && gl->live;
-    TreeView tv;
-    int first_player = 1;
-    if (active) { tv = tree_view(st, g, st.cur[g]); first_player = gl->first_player; }
+    if (active && lane == 0) gl->arena = st.cur[g];
+    wave_sync();
     long long n_eval = 0;
     Prof prof;
     prof.start(st.stamps);
@@ -81,6 +80,7 @@ __global__ __launch_bounds__(256, (F16 && MODE == 0 && N <= 8) ? 2 : 1) void sea
         Descent d = {0, 0, 0, 0};
         int term = 0;
         if (active) {
+            const TreeView tv = tree_view(st, g, gl->arena);
             d = wave_select(st, tv, gl, lane);
             term = wave_game_end(gl->leaf_bb, st.N, st.S, st.n_in_row, d.ply, lane);
             if (lane == 0) { gl->term = term; gl->need_eval = term == 0; }
@@ -105,7 +105,14 @@ __global__ __launch_bounds__(256, (F16 && MODE == 0 && N <= 8) ? 2 : 1) void sea
             }
         }
         if (active) {
-            const int cur_player = player_at(first_player, d.ply);
+            if (MODE == 0) {
+                // nothing of the descent is kept in registers across the CNN: it is re-read
+                // from the game's LDS record (written before the barrier that opened the CNN)
+                d.leaf = gl->leaf; d.depth = gl->depth; d.ply = gl->leaf_ply; d.last = gl->leaf_last;
+                term = gl->term;
+            }
+            const TreeView tv = tree_view(st, g, gl->arena);
+            const int cur_player = player_at(gl->first_player, d.ply);
             double v;
             if (term) {
                 // mcts_alphaZero.py:139-145: tie 0, else +1 if the winner is to move, else -1

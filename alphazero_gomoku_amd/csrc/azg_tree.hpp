@@ -30,6 +30,8 @@ struct GameLds {
     u64 leaf_bb[2][MAXW];
     int path[MAXS + 1];        // edge indices root .. leaf
     int depth;                 // entries in path
+    int leaf;                  // edge index of the leaf (= path[depth-1])
+    int arena;                 // live arena of the game's tree
     int root_ply, root_last, first_player;
     int leaf_ply, leaf_last;
     int live;
@@ -169,7 +171,7 @@ __device__ inline Descent wave_select(const DevState &st, const TreeView &t, Gam
         ply++;
         last = act;
     }
-    if (lane == 0) { gl->depth = depth; gl->leaf_ply = ply; gl->leaf_last = last; }
+    if (lane == 0) { gl->depth = depth; gl->leaf = e; gl->leaf_ply = ply; gl->leaf_last = last; }
     wave_sync();
     Descent d;
     d.leaf = e; d.depth = depth; d.ply = ply; d.last = last;
