@@ -34,8 +34,9 @@ struct azg_handle {
     // pinned staging
     double *h_noise = nullptr, *h_u = nullptr;
     int *h_moves = nullptr;
-    signed char *h_sc = nullptr;     // status | winner
-    int *h_ints = nullptr;           // ply | s_count | err
+    int *h_ints = nullptr;           // pinned copy of the mirror block: ply | s_count | err | status | winner
+    int *d_mirror = nullptr;         // device block the five arrays above live in (one copy per refresh)
+    bool mirrors_fresh = false;
     double *d_noise = nullptr, *d_u = nullptr, *d_pi = nullptr;
     int *d_moves = nullptr, *d_given = nullptr;
     // grow-on-demand device scratch
@@ -159,19 +160,17 @@ static int harvest_events(azg_handle *h)
 static int refresh_mirrors(azg_handle *h)
 {
     const int B = h->cfg.n_games;
-    HIPCHK(h, hipMemcpyAsync(h->h_sc, h->st.status, B, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipMemcpyAsync(h->h_sc + B, h->st.winner, B, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipMemcpyAsync(h->h_ints, h->st.ply, B * sizeof(int), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipMemcpyAsync(h->h_ints + B, h->st.s_count, B * sizeof(int), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipMemcpyAsync(h->h_ints + 2 * B, h->st.err, B * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->h_ints, h->d_mirror, (size_t)B * 14, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     for (int g = 0; g < B; g++) {
-        h->h_status[g] = h->h_sc[g];
-        h->h_winner[g] = h->h_sc[B + g];
+        const signed char *sc = reinterpret_cast<const signed char *>(h->h_ints + 3 * B);
+        h->h_status[g] = sc[g];
+        h->h_winner[g] = sc[B + g];
         h->h_ply[g] = h->h_ints[g];
         h->h_scount[g] = h->h_ints[B + g];
         h->h_err[g] = h->h_ints[2 * B + g];
     }
+    h->mirrors_fresh = true;
     int rc = harvest_events(h);
     if (rc) return rc;
     for (int g = 0; g < B; g++) {
@@ -195,7 +194,6 @@ extern "C" void azg_destroy(azg_handle *h)
     if (h->h_noise) (void)hipHostFree(h->h_noise);
     if (h->h_u) (void)hipHostFree(h->h_u);
     if (h->h_moves) (void)hipHostFree(h->h_moves);
-    if (h->h_sc) (void)hipHostFree(h->h_sc);
     if (h->h_ints) (void)hipHostFree(h->h_ints);
     for (auto &e : h->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -215,12 +213,14 @@ static int create_impl(azg_handle *h)
     const size_t E = (size_t)B * 2 * st.cap;
     int rc;
     if ((rc = dev_alloc(h, &st.bb, (size_t)B * 2 * MAXW))) return rc;
-    if ((rc = dev_alloc(h, &st.ply, B))) return rc;
+    if ((rc = dev_alloc(h, &h->d_mirror, ((size_t)B * 14 + 3) / 4 + 4))) return rc;
+    st.ply = h->d_mirror;
+    st.s_count = h->d_mirror + B;
+    st.err = h->d_mirror + 2 * B;
+    st.status = reinterpret_cast<signed char *>(h->d_mirror + 3 * B);
+    st.winner = st.status + B;
     if ((rc = dev_alloc(h, &st.last_move, B))) return rc;
     if ((rc = dev_alloc(h, &st.first_player, B))) return rc;
-    if ((rc = dev_alloc(h, &st.status, B))) return rc;
-    if ((rc = dev_alloc(h, &st.winner, B))) return rc;
-    if ((rc = dev_alloc(h, &st.err, B))) return rc;
     if ((rc = dev_alloc(h, &st.eP, E, false))) return rc;
     if ((rc = dev_alloc(h, &st.eN, E, false))) return rc;
     if ((rc = dev_alloc(h, &st.eQ, E, false))) return rc;
@@ -233,7 +233,6 @@ static int create_impl(azg_handle *h)
     if ((rc = dev_alloc(h, &st.s_last, (size_t)B * S, false))) return rc;
     if ((rc = dev_alloc(h, &st.s_ply, (size_t)B * S, false))) return rc;
     if ((rc = dev_alloc(h, &st.s_pi, (size_t)B * S * S, false))) return rc;
-    if ((rc = dev_alloc(h, &st.s_count, B))) return rc;
     if ((rc = dev_alloc(h, &st.game_id, B))) return rc;
     if ((rc = dev_alloc(h, &st.drained, B))) return rc;
     if ((rc = dev_alloc(h, &st.stamps, 32))) return rc;
@@ -245,8 +244,7 @@ static int create_impl(azg_handle *h)
     HIPCHK(h, hipHostMalloc((void **)&h->h_noise, (size_t)B * S * sizeof(double)));
     HIPCHK(h, hipHostMalloc((void **)&h->h_u, (size_t)B * sizeof(double)));
     HIPCHK(h, hipHostMalloc((void **)&h->h_moves, (size_t)B * sizeof(int)));
-    HIPCHK(h, hipHostMalloc((void **)&h->h_sc, (size_t)B * 2));
-    HIPCHK(h, hipHostMalloc((void **)&h->h_ints, (size_t)B * 3 * sizeof(int)));
+    HIPCHK(h, hipHostMalloc((void **)&h->h_ints, (size_t)B * 14 + 16));
     h->h_ply.assign(B, 0); h->h_scount.assign(B, 0); h->h_err.assign(B, 0);
     h->h_status.assign(B, 2); h->h_winner.assign(B, -1); h->h_drained.assign(B, 1);
     h->rng.resize(B);
@@ -481,6 +479,7 @@ extern "C" int azg_search(azg_handle *h)
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipEventRecord(ev.second, h->stream));
     h->ev_pending++;
+    h->mirrors_fresh = false;
     return AZG_OK;
 }
 
@@ -580,7 +579,9 @@ extern "C" int azg_status(azg_handle *h, uint8_t *ended, int8_t *winner, int32_t
 {
     if (!h) return AZG_EINVAL;
     HIPCHK(h, hipSetDevice(h->cfg.device));
-    int rc = refresh_mirrors(h);
+    // every call that changes a game's state ends with a refresh, so the host copy is
+    // normally current; only a search (which can raise the arena-overflow flag) is not
+    int rc = h->mirrors_fresh ? AZG_OK : refresh_mirrors(h);
     const int B = h->cfg.n_games;
     for (int g = 0; g < B; g++) {
         if (ended) ended[g] = h->h_status[g] == 1;

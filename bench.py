@@ -22,7 +22,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 FLOP_PER_EVAL = {6: 6.79e6, 8: 12.09e6, 15: 42.80e6}    # 188416*S + 8*S*S + 128, 2 flop / MAC
-PEAK_F32_MFMA_TFLOPS = 157.3                              # dense f32-input MFMA peak of MI355X
+PEAK_TFLOPS = {"f16x3": 2500.0, "f32": 157.3}            # dense MFMA peaks of MI355X: f16 inputs / f32 inputs
 
 
 def random_init_params(n, device):
@@ -62,6 +62,8 @@ def main():
     ap.add_argument("--n-in-row", type=int, default=5)
     ap.add_argument("--playouts", type=int, default=400)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cnn", choices=["f16x3", "f32"], default="f16x3",
+                    help="conv arithmetic: split-f16 MFMA (three products, f32 accumulate) or f32-input MFMA")
     args = ap.parse_args()
 
     import torch
@@ -69,7 +71,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1:
+    use_dist = world > 1 or "RANK" in os.environ
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         torch.cuda.set_device(local_rank)
@@ -83,7 +86,8 @@ def main():
 
     n, k = args.board, args.n_in_row
     params = random_init_params(n, dev)
-    eng = az.SelfPlayEngine(n, k, args.playouts, args.games, 5.0, device=local_rank)
+    eng = az.SelfPlayEngine(n, k, args.playouts, args.games, 5.0, device=local_rank,
+                            cnn_mode=az._lib.CNN_F16X3 if args.cnn == "f16x3" else az._lib.CNN_F32)
     eng.set_weights(params)
     drained = []
     run = SelfPlayRunner(eng, temp=1.0, seed0=0, first_game_id=rank, game_id_stride=world,
@@ -93,7 +97,7 @@ def main():
         run.step()
     drained.clear()
     eng.profile()                                   # reset the kernel timers
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     g0, p0 = run.games_done, run.plies_done
@@ -101,7 +105,7 @@ def main():
     for _ in range(args.steps):
         run.step()
     gathered = 0
-    if world > 1:
+    if use_dist:
         # the (state, pi, z) gather of the sharded configuration: every rank ends up with
         # every rank's tuples of the timed region (RCCL all_gather over xGMI)
         if drained:
@@ -113,14 +117,14 @@ def main():
         allt = azdist.gather_samples(mine)
         gathered = int(allt["z"].shape[0])
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     dt = time.perf_counter() - t0
     games, plies = run.games_done - g0, run.plies_done - p0
     launches, kernel_ms, evals = eng.profile()
 
     stats = torch.tensor([dt, games, plies, evals, kernel_ms, launches], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_dist:
         mx = stats.clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         sm = stats.clone()
@@ -137,7 +141,9 @@ def main():
             "metric": "completed self-play games/sec, %dx%d board n_playout=%d" % (n, n, args.playouts),
             "value": games / dt, "unit": "games/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None,
+            "dtype": "f16x3 (f32 operands split into two halves, three f16 MFMAs per product, f32 accumulate; tree in f64)" if args.cnn == "f16x3" else "f32",
+            "data": "synthetic",
             "config": {"workload": "%dx%d board %d-in-row, n_playout=%d, %d parallel self-play games per MI355X, "
                                    "random-init net (torch.manual_seed(0) default init), empty-board starts, "
                                    "c_puct=5, temp=1, Dirichlet(0.1) mix 0.25, tree reuse, finished slots refilled"
@@ -147,8 +153,10 @@ def main():
             "games_completed": games, "plies_per_game": plies / games if games else None,
             "playouts_per_s": evals / dt, "samples_gathered": gathered,
             "roofline": {"bound": "mfma", "kernel": "search_kernel (fused select + leaf CNN + expand + backup)",
-                         "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                         "achieved": achieved, "peak": PEAK_TFLOPS[args.cnn], "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_TFLOPS[args.cnn], "traffic": None,
+                         "note": "achieved counts the ALGORITHMIC flops of the leaf CNN (12.09 MFLOP per evaluation at 8x8); "
+                                 "the f16x3 path issues ~2.9x that many MFMA flops",
                          "launches": launches, "avg_launch_ms": kernel_ms / launches if launches else None,
                          "flop_per_leaf_eval": flop, "leaf_evals_per_launch": evals_per_gpu / launches if launches else None},
         }
@@ -156,7 +164,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(n, k, args.playouts, [p.cpu().numpy() for p in params])
         print(json.dumps(out))
     eng.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
