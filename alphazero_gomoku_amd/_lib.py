@@ -4,7 +4,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libazgomoku.so")
+# AZG_LIBRARY selects another build of the same library (A/B timing of kernel variants)
+LIB_PATH = os.environ.get("AZG_LIBRARY") or os.path.join(_HERE, "libazgomoku.so")
 
 PRIOR_NET, PRIOR_UNIFORM32, PRIOR_HASH = 0, 1, 2
 LAYOUT_TORCH, LAYOUT_THEANO = 0, 1

@@ -36,7 +36,7 @@ struct Cnn16Geom {
     static constexpr int NT = (NP + 31) / 32;
     static constexpr int NTP = NT * 32;
     static constexpr int ROWS = NP + 1;                       // + the all-zero row
-    static constexpr bool BPF = false;                        // explicit LDS prefetch (costs 8 registers per tile)
+    static constexpr bool BPF = true;                         // explicit LDS prefetch (costs 8 registers per tile)
     // row strides in bytes (channels * 2 + 16 pad)
     static constexpr int RS_IN = 16 * 2 + 16, RS_A1 = 32 * 2 + 16, RS_A2 = 64 * 2 + 16;
     // LDS map in bytes
@@ -45,30 +45,67 @@ struct Cnn16Geom {
     static constexpr int A1L_OFF = A1H_OFF + ROWS * RS_A1;
     static constexpr int A2H_OFF = A1L_OFF + ROWS * RS_A1;
     static constexpr int A2L_OFF = A2H_OFF + ROWS * RS_A2;
-    static constexpr int WH_OFF = A2L_OFF + ROWS * RS_A2;     // head weights f32 [6][128]
-    static constexpr int END_BYTES = WH_OFF + 6 * 128 * 4;
+    static constexpr int WH_OFF = A2L_OFF + ROWS * RS_A2;     // head weights as halves (4 KB, layout of pack_head16)
+    static constexpr int BIAS_OFF = WH_OFF + 4096;            // f32: conv1 [32], conv2 [64], conv3 [128], heads [6 + 2 pad]
+    static constexpr int END_BYTES = BIAS_OFF + (32 + 64 + 128 + 8) * 4;
     static constexpr int END = (END_BYTES + 3) / 4;           // in floats, like CnnGeom::END
+    // fully connected layers as MFMA GEMMs: D[output][leaf] = sum_k W[output][k] * x[k][leaf];
+    // every wave takes a quarter of the k-steps of every output tile
+    static constexpr int KWP = ((4 * S + 15) / 16 + 3) / 4;   // k-steps per wave, act_fc1
+    static constexpr int KWV = ((2 * S + 15) / 16 + 3) / 4;   // k-steps per wave, val_fc1
+    static constexpr int KPP = 4 * KWP * 16, KPV = 4 * KWV * 16;   // padded input lengths
+    static constexpr int OTP = (S + 31) / 32;                 // output tiles of act_fc1 (val_fc1 has 2)
+    static constexpr int OC = OTP < 4 ? OTP : 4;              // output tiles per accumulator group
+    static constexpr int NOUT = OTP * 32 + 64;
+    static_assert(OTP % OC == 0, "act_fc1 output tiles must split evenly into accumulator groups");
     // f32 scratch that aliases IN + A1 once conv2 has consumed them (float offsets)
-    static constexpr int VL = (2 * S + 3) & ~3;
-    static constexpr int HFS = 4 * S + VL;
-    static constexpr int HP_OFF = 0;
-    static constexpr int HF_OFF = HP_OFF + 24 * NTP;
-    static constexpr int LG_OFF = HF_OFF + T_ * HFS;
-    static constexpr int HD_OFF = LG_OFF + T_ * S;
-    static constexpr int VAL_OFF = HD_OFF + T_ * 64;
-    static_assert((VAL_OFF + T_) * 4 <= A2H_OFF, "scratch does not fit under IN+A1");
+    static constexpr int HP_OFF = 0;                          // head partials [4 waves][6][NTP]
+    static constexpr int PART_OFF = 0;                        // FC partials [4 waves][NOUT][T] (HP is dead by then)
+    static constexpr int LG_OFF = PART_OFF + 4 * NOUT * T_;   // probabilities [T][S]
+    static constexpr int VAL_OFF = LG_OFF + T_ * S;           // values [T]
+    static constexpr int X_OFF = HP_OFF + 24 * NTP;           // head outputs as halves: hi [T][KPP], lo [T][KPP], hi [T][KPV], lo [T][KPV]
+    static constexpr int X_END = X_OFF + T_ * (KPP + KPV);
+    static_assert(VAL_OFF + T_ <= X_OFF, "FC partials and results must fit in the head-partial region");
+    static_assert(X_END * 4 <= A2H_OFF, "scratch does not fit under IN+A1");
     static_assert(T_ <= 4, "one wave per position in the softmax stage");
     static_assert(END_BYTES % 8 == 0, "GameLds behind the CNN region needs 8-byte alignment");
 };
+
+// The weight (A operand) stream of one wave for one layer runs RING k-steps ahead of the
+// MFMAs in a ring of register pairs.  conv_preload requests the first RING k-steps; it is
+// called well before the layer starts (during the previous layer or the input fill) so that
+// the L2 latency of the first k-steps is not exposed after the barrier that opens the layer.
+template <int RING>
+struct WRing {
+    half8 ah[RING], al[RING];
+};
+
+template <int CINP, int COUT, int RING>
+__device__ inline gptr<half8> conv_wrow(const half8 *wp, int wave, int lane)
+{
+    constexpr int CT = COUT / 32, KS = 9 * (CINP / 16);
+    return as_global(wp + ((size_t)(wave % CT) * KS * 64 + lane) * 2);
+}
+
+template <int CINP, int COUT, int RING>
+__device__ inline void conv_preload(const half8 *wp, int wave, int lane, WRing<RING> &r)
+{
+    constexpr int KS = 9 * (CINP / 16);
+    static_assert(RING <= KS, "ring deeper than the layer");
+    const gptr<half8> wrow = conv_wrow<CINP, COUT, RING>(wp, wave, lane);
+#pragma unroll
+    for (int d = 0; d < RING; d++) { r.ah[d] = wrow[(size_t)d * 128]; r.al[d] = wrow[(size_t)d * 128 + 1]; }
+    __builtin_amdgcn_sched_barrier(0);
+}
 
 // One 3x3 convolution layer on split-f16 operands.  CINP = input channels padded to a
 // multiple of 16.  wp: packed weights, per (cotile, kstep = tap*CG + cg) and lane 16
 // halves: 8 hi then 8 lo of W[co = cotile*32 + (lane&31)][ci = cg*16 + 8*(lane>>5) + j].
 // XLO = false skips the w_hi*x_lo term (exact inputs).  xh / xl: hi / lo image
-// ([NP rows + zero row][RS bytes]).
-template <class G, int CINP, int COUT, int RS, bool XLO, bool BPF, class Epi>
-__device__ inline void conv3x3_f16(const half8 *wp, const char *xh, const char *xl, int wave, int lane,
-                                   Epi epi)
+// ([NP rows + zero row][RS bytes]).  ring: filled by conv_preload for the same layer.
+template <class G, int CINP, int COUT, int RS, bool XLO, bool BPF, int RING, class Epi>
+__device__ inline void conv3x3_f16(const half8 *wp, WRing<RING> &ring, const char *xh, const char *xl, int wave,
+                                   int lane, Epi epi, Prof *prof = nullptr, int slot = 11)
 {
     constexpr int CT = COUT / 32;
     constexpr int WPC = 4 / CT;
@@ -94,12 +131,12 @@ __device__ inline void conv3x3_f16(const half8 *wp, const char *xh, const char *
             const int row = cell / G::N, col = cell - row * G::N;
             base[i] = p * RS + half * 16;
             prow[i] = p;
-            unsigned m = 0;
-#pragma unroll
-            for (int t = 0; t < 9; t++) {
-                const int r2 = row + t / 3 - 1, c2 = col + t % 3 - 1;
-                if (r2 >= 0 && r2 < G::N && c2 >= 0 && c2 < G::N) m |= 1u << t;
-            }
+            // taps t = 3*(dr+1) + (dc+1) that stay on the board
+            unsigned m = 0x1FFu;
+            if (row == 0) m &= ~0x007u;
+            if (row == G::N - 1) m &= ~0x1C0u;
+            if (col == 0) m &= ~0x049u;
+            if (col == G::N - 1) m &= ~0x124u;
             vmask[i] = m;
         }
     }
@@ -110,21 +147,15 @@ __device__ inline void conv3x3_f16(const half8 *wp, const char *xh, const char *
     };
 
     f32x16 acc[PT];
-#pragma unroll
-    for (int i = 0; i < PT; i++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) acc[i][r] = 0.0f;
+    const f32x16 zacc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (prof && slot != 11) prof->mark(slot - 1);
 
     // Software pipeline, fully unrolled (KS <= 36) so that every ring index and every
-    // address offset is a compile-time constant: weights (global, L2 resident) run three
-    // k-steps ahead in a ring of three register pairs, activations (LDS) one k-step ahead
-    // in two register sets, so the MFMAs of a step never wait for a load of that step.
-    const gptr<half8> wrow = as_global(wp + ((size_t)cot * KS * 64 + lane) * 2);
-    half8 ah[3], al[3];
-#pragma unroll
-    for (int d = 0; d < 3; d++) {
-        if (d < KS) { ah[d] = wrow[(size_t)d * 128]; al[d] = wrow[(size_t)d * 128 + 1]; }
-    }
+    // address offset is a compile-time constant: weights (global, L2 resident) run RING
+    // k-steps ahead, activations (LDS) one k-step ahead in two register sets, so the MFMAs
+    // of a step never wait for a load of that step.
+    const gptr<half8> wrow = conv_wrow<CINP, COUT, RING>(wp, wave, lane);
+    half8 (&ah)[RING] = ring.ah, (&al)[RING] = ring.al;
     // BPF (activation prefetch) costs 8*PT registers; the two-workgroups-per-CU builds drop it
     // and let the other workgroup's waves cover the LDS latency instead.
     constexpr int NB = BPF ? 2 : 1;
@@ -138,7 +169,7 @@ __device__ inline void conv3x3_f16(const half8 *wp, const char *xh, const char *
     }
 #pragma unroll
     for (int ks = 0; ks < KS; ks++) {
-        const int cb = BPF ? (ks & 1) : 0, nb = BPF ? (cb ^ 1) : 0, ca = ks % 3;
+        const int cb = BPF ? (ks & 1) : 0, nb = BPF ? (cb ^ 1) : 0, ca = ks % RING;
         const int lk = BPF ? ks + 1 : ks;                      // k-step whose activations are loaded now
         if (lk < KS) {
 #pragma unroll
@@ -149,21 +180,189 @@ __device__ inline void conv3x3_f16(const half8 *wp, const char *xh, const char *
             }
         }
         const half8 wa = ah[ca], wl = al[ca];
-        if (ks + 3 < KS) { ah[ca] = wrow[(size_t)(ks + 3) * 128]; al[ca] = wrow[(size_t)(ks + 3) * 128 + 1]; }
-        // keep the loads above and the MFMAs below in this order: left alone, the
-        // scheduler sinks each load to just before its first use and waits for it there
-        __builtin_amdgcn_sched_barrier(0);
+        if (ks + RING < KS) { ah[ca] = wrow[(size_t)(ks + RING) * 128]; al[ca] = wrow[(size_t)(ks + RING) * 128 + 1]; }
 #pragma unroll
         for (int i = 0; i < PT; i++) {
-            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa, bh[cb][i], acc[i], 0, 0, 0);
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa, bh[cb][i], ks == 0 ? zacc : acc[i], 0, 0, 0);
             acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, bh[cb][i], acc[i], 0, 0, 0);
             if (XLO) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa, bl[cb][i], acc[i], 0, 0, 0);
         }
+        // Issue order inside the k-step: the loads of later k-steps and their address
+        // arithmetic are spread between this step's MFMAs (an MFMA occupies the matrix pipe for
+        // 32 cycles but the issue port for 8).  Left alone the scheduler sinks each load to
+        // just before its first use and waits for it there; fenced off as one block in front
+        // of the MFMAs they leave the matrix pipe idle while they issue.
+        if (BPF) {
+            constexpr int NM = PT * (XLO ? 3 : 2), NDS = PT * (XLO ? 2 : 1);
+#pragma unroll
+            for (int m = 0; m < NM; m++) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                 // one MFMA
+                __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);                 // two VALU (addresses)
+                if (m < NDS) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);    // one LDS read
+                if (m >= NM - 2) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); // one global read
+            }
+        }
         __builtin_amdgcn_sched_barrier(0);
     }
+    if (prof) prof->mark(slot);
 #pragma unroll
     for (int i = 0; i < PT; i++)
-        if (prow[i] >= 0) epi(i, sub * PT + i, acc[i], prow[i]);
+        if (sub * PT + i < G::NT) epi(i, sub * PT + i, acc[i], prow[i]);   // wave-uniform: epilogues may use MFMA
+}
+
+// Everything after conv3 for the split-f16 path: head outputs (bias + the four channel-tile
+// partials, ReLU) written as half pairs, both fully connected layers on the matrix cores,
+// softmax and tanh.  A wave takes k-steps [wave*KW, (wave+1)*KW) of every 32-output tile; the
+// four partial sums per output meet in LDS and are added in a fixed order.  All A operands of
+// a wave (or the first RING of them) are requested before the head outputs are formed, so the
+// L2 latency of the weight stream overlaps that stage.
+template <class G>
+__device__ inline void cnn16_tail(const NetWeights &nw, float *lds, int tid, Prof &prof)
+{
+    char *ldb = reinterpret_cast<char *>(lds);
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int half = lane >> 5, n = lane & 31;
+    constexpr int NUP = G::OTP * G::KWP, NU = NUP + 2 * G::KWV;     // (k-step, tile) units per wave
+    constexpr int RING = NU < 12 ? NU : 12;
+
+    struct Unit { int fc, grp, kk, tile, ntile, last; };
+    auto unit = [](int u) {
+        Unit q;
+        if (u < NUP) {
+            q.fc = 0; q.grp = u / (G::KWP * G::OC);
+            const int rem = u - q.grp * G::KWP * G::OC;
+            q.kk = rem / G::OC; q.tile = rem - q.kk * G::OC; q.ntile = G::OC;
+            q.last = q.kk == G::KWP - 1 && q.tile == G::OC - 1;
+        } else {
+            const int v = u - NUP;
+            q.fc = 1; q.grp = 0; q.kk = v / 2; q.tile = v - 2 * q.kk; q.ntile = 2;
+            q.last = q.kk == G::KWV - 1 && q.tile == 1;
+        }
+        return q;
+    };
+    const gptr<half8> wp[2] = {as_global(reinterpret_cast<const half8 *>(nw.wfc16[0])),
+                               as_global(reinterpret_cast<const half8 *>(nw.wfc16[1]))};
+    auto wsrc = [&](int u) {
+        const Unit q = unit(u);
+        const int kw = q.fc ? G::KWV : G::KWP;
+        const int ot = q.grp * G::OC + q.tile, ks = wave * kw + q.kk;
+        return wp[q.fc] + (((size_t)ot * (4 * kw) + ks) * 64 + lane) * 2;
+    };
+    half8 ah[RING], al[RING];
+#pragma unroll
+    for (int u = 0; u < RING; u++) { const gptr<half8> s = wsrc(u); ah[u] = s[0]; al[u] = s[1]; }
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- head outputs, flattened [c][row][col] per head like the reference's view(-1, ...)
+    {
+        const float *bh = lds + G::BIAS_OFF / 4 + 224;
+        _Float16 *xb = reinterpret_cast<_Float16 *>(lds + G::X_OFF);
+        for (int e = tid; e < G::T * (G::KPP + G::KPV); e += 256) {
+            const bool pol = e < G::T * G::KPP;
+            const int e2 = pol ? e : e - G::T * G::KPP;
+            const int kp = pol ? G::KPP : G::KPV;
+            const int leaf = e2 / kp, k = e2 - leaf * kp;
+            float s = 0.0f;
+            if (k < (pol ? 4 : 2) * G::S) {
+                const int cc = k / G::S, cell = k - cc * G::S;
+                const int c = pol ? cc : 4 + cc, p = leaf * G::S + cell;
+                const float *pp = lds + G::HP_OFF + c * G::NTP + p;
+                s = __builtin_fmaf((pp[0] + pp[6 * G::NTP]) + (pp[12 * G::NTP] + pp[18 * G::NTP]), kWUnscale, bh[c]);
+                s = s > 0.0f ? s : 0.0f;
+            }
+            const _Float16 hi = (_Float16)s;
+            _Float16 *dst = xb + (pol ? 0 : 2 * G::T * G::KPP) + leaf * kp + k;
+            dst[0] = hi;
+            dst[G::T * kp] = (_Float16)(s - (float)hi);
+        }
+    }
+    __syncthreads();
+    prof.mark(7);
+
+    // ---- act_fc1 and val_fc1
+    {
+        const half8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
+        const int leafc = n < G::T ? n : 0;
+        f32x16 acc[G::OC];
+        half8 xh = z8, xl = z8;
+#pragma unroll
+        for (int u = 0; u < NU; u++) {
+            const Unit q = unit(u);
+            const int kw = q.fc ? G::KWV : G::KWP, kp = q.fc ? G::KPV : G::KPP;
+            if (q.tile == 0) {
+                const char *xi = ldb + G::X_OFF * 4 + (q.fc ? 2 * G::T * G::KPP * 2 : 0)
+                                 + (leafc * kp + (wave * kw + q.kk) * 16 + 8 * half) * 2;
+                xh = *reinterpret_cast<const half8 *>(xi);
+                xl = *reinterpret_cast<const half8 *>(xi + G::T * kp * 2);
+                if (n >= G::T) { xh = z8; xl = z8; }
+                if (q.kk == 0) {
+#pragma unroll
+                    for (int i = 0; i < G::OC; i++)
+#pragma unroll
+                        for (int r = 0; r < 16; r++) acc[i][r] = 0.0f;
+                }
+            }
+            const half8 wa = ah[u % RING], wl = al[u % RING];
+            if (u + RING < NU) { const gptr<half8> s = wsrc(u + RING); ah[u % RING] = s[0]; al[u % RING] = s[1]; }
+            acc[q.tile] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa, xh, acc[q.tile], 0, 0, 0);
+            acc[q.tile] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, xh, acc[q.tile], 0, 0, 0);
+            acc[q.tile] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa, xl, acc[q.tile], 0, 0, 0);
+            if (q.last && n < G::T) {
+#pragma unroll
+                for (int i = 0; i < q.ntile; i++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++) {
+                        const int o = (q.fc ? G::OTP * 32 : q.grp * G::OC * 32) + i * 32 + acc_row(r, half);
+                        lds[G::PART_OFF + (wave * G::NOUT + o) * G::T + n] = acc[i][r];
+                    }
+            }
+        }
+    }
+    __syncthreads();
+    prof.mark(8);
+
+    // ---- softmax over the S logits and the scalar value, one wave per position
+    if (wave < G::T) {
+        const int leaf = wave;
+        auto fc_out = [&](int o, float bias) {
+            const float *pp = lds + G::PART_OFF + o * G::T + leaf;
+            const float s = (pp[0] + pp[G::NOUT * G::T]) + (pp[2 * G::NOUT * G::T] + pp[3 * G::NOUT * G::T]);
+            return __builtin_fmaf(s, kWUnscale, bias);
+        };
+        constexpr int PER = (G::S + 63) / 64;
+        float x[PER];
+        float mx = -3.0e38f;
+#pragma unroll
+        for (int i = 0; i < PER; i++) {
+            const int a = lane + 64 * i;
+            x[i] = a < G::S ? fc_out(a, nw.bpfc[a]) : -3.0e38f;
+            mx = fmaxf(mx, x[i]);
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+        float sum = 0.0f;
+#pragma unroll
+        for (int i = 0; i < PER; i++) {
+            const int a = lane + 64 * i;
+            if (a < G::S) sum += expf(x[i] - mx);
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off);
+        const float lse = logf(sum);
+#pragma unroll
+        for (int i = 0; i < PER; i++) {
+            const int a = lane + 64 * i;
+            if (a < G::S) lds[G::LG_OFF + leaf * G::S + a] = expf((x[i] - mx) - lse);
+        }
+        float hdn = fc_out(G::OTP * 32 + lane, nw.bvfc1[lane]);
+        hdn = hdn > 0.0f ? hdn : 0.0f;
+        float v = hdn * nw.wvfc2[lane];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+        if (lane == 0) lds[G::VAL_OFF + leaf] = tanhf(v + nw.bvfc2[0]);
+    }
+    __syncthreads();
+    prof.mark(9);
 }
 
 // Full forward; interface as cnn_forward (azg_cnn.hpp): results at lds[LG_OFF..] / lds[VAL_OFF..]
@@ -173,10 +372,23 @@ __device__ inline void cnn16_forward(const NetWeights &nw_in, float *lds, InputF
 {
     const NetWeights nw = opaque_weights(nw_in);
     char *ldb = reinterpret_cast<char *>(lds);
-    const int tid = threadIdx.x;
-    const int wave = tid >> 6, lane = tid & 63;
+    // The thread index is re-read opaquely on every call: per-lane addresses and masks derived
+    // from it would otherwise be hoisted out of the caller's playout loop and held in registers.
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int half = lane >> 5, j = lane & 31;
     const half8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
+
+    const float *lbias = lds + G::BIAS_OFF / 4;            // conv1 | conv2 | conv3 | head biases
+    constexpr int R1 = 9, R2 = 6, R3 = 3;                 // k-steps of weights in flight per layer
+    const half8 *w1 = reinterpret_cast<const half8 *>(nw.w16[0]);
+    const half8 *w2 = reinterpret_cast<const half8 *>(nw.w16[1]);
+    const half8 *w3 = reinterpret_cast<const half8 *>(nw.w16[2]);
+    WRing<R1> ring1;
+    WRing<R2> ring2;
+    WRing<R3> ring3;
+    conv_preload<16, 32, R1>(w1, wave, lane, ring1);
 
     // ---- input image: the 4 planes as halves in channels 0..3 of a 16-channel row; the
     //      zero rows of the IN and A1 images are rewritten (the f32 scratch overlaps them)
@@ -200,6 +412,7 @@ __device__ inline void cnn16_forward(const NetWeights &nw_in, float *lds, InputF
     // epilogue of conv1/conv2: scale back, bias, ReLU, split into halves, store [pos][channel]
     auto store_split = [&](const float *bias, int cobase, char *oh, char *ol, int rs) {
         return [=](int, int, const f32x16 &acc, int p) {
+            if (p < 0) return;                              // padding lane of the last tile
 #pragma unroll
             for (int g = 0; g < 4; g++) {
                 half4 h, l;
@@ -218,47 +431,67 @@ __device__ inline void cnn16_forward(const NetWeights &nw_in, float *lds, InputF
             }
         };
     };
-    conv3x3_f16<G, 16, 32, G::RS_IN, false, G::BPF>(reinterpret_cast<const half8 *>(nw.w16[0]), ldb + G::IN_OFF,
-                                            ldb + G::IN_OFF, wave, lane,
-                                            store_split(nw.bconv[0], 0, ldb + G::A1H_OFF, ldb + G::A1L_OFF, G::RS_A1));
+    conv_preload<32, 64, R2>(w2, wave, lane, ring2);
+    conv3x3_f16<G, 16, 32, G::RS_IN, false, G::BPF, R1>(w1, ring1, ldb + G::IN_OFF, ldb + G::IN_OFF, wave, lane,
+                                                store_split(lbias, 0, ldb + G::A1H_OFF, ldb + G::A1L_OFF, G::RS_A1), &prof, 13);
+    prof.mark(16);
     __syncthreads();
     prof.mark(3);
-    conv3x3_f16<G, 32, 64, G::RS_A1, true, G::BPF>(reinterpret_cast<const half8 *>(nw.w16[1]), ldb + G::A1H_OFF,
-                                           ldb + G::A1L_OFF, wave, lane,
-                                           store_split(nw.bconv[1], (wave % 2) * 32, ldb + G::A2H_OFF,
-                                                       ldb + G::A2L_OFF, G::RS_A2));
+    conv_preload<64, 128, R3>(w3, wave, lane, ring3);
+    conv3x3_f16<G, 32, 64, G::RS_A1, true, G::BPF, R2>(w2, ring2, ldb + G::A1H_OFF, ldb + G::A1L_OFF, wave, lane,
+                                               store_split(lbias + 32, (wave % 2) * 32, ldb + G::A2H_OFF,
+                                                           ldb + G::A2L_OFF, G::RS_A2), &prof, 15);
+    prof.mark(17);
     __syncthreads();
     prof.mark(4);
 
-    // ---- conv3 with the two 1x1 heads reduced from the accumulators (float32 VALU)
+    // ---- conv3; its output never goes to LDS: bias + ReLU in registers, split into halves,
+    //      and the accumulator registers are the B operand of the MFMA that applies the two
+    //      1x1 head convolutions (k runs over this wave's 32 channels in accumulator order,
+    //      the head weights are packed to match).  The four waves' partial sums meet in LDS.
     {
-        const float *wh = lds + G::WH_OFF / 4;
-        const float *b3 = nw.bconv[2];
+        const float *b3 = lbias + 96 + wave * 32;
         float *hp = lds + G::HP_OFF + wave * 6 * G::NTP;
-        conv3x3_f16<G, 64, 128, G::RS_A2, true, G::BPF>(reinterpret_cast<const half8 *>(nw.w16[2]), ldb + G::A2H_OFF,
-                                                ldb + G::A2L_OFF, wave, lane,
-            [=](int, int tile, const f32x16 &acc, int) {
-                float s[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        const char *whp = ldb + G::WH_OFF + ((wave * 4 + half) * 8 + (j < 8 ? j : 7)) * 32;
+        conv3x3_f16<G, 64, 128, G::RS_A2, true, G::BPF, R3>(w3, ring3, ldb + G::A2H_OFF, ldb + G::A2L_OFF, wave, lane,
+            [=](int, int tile, const f32x16 &acc, int p) {
+                const f32x16 zacc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                f32x16 hd = zacc;
 #pragma unroll
-                for (int r = 0; r < 16; r++) {
-                    const int co = wave * 32 + acc_row(r, half);
-                    float v = __builtin_fmaf(acc[r], kWUnscale, b3[co]);
-                    v = v > 0.0f ? v : 0.0f;
+                for (int s2 = 0; s2 < 2; s2++) {
+                    half8 xh8, xl8;
 #pragma unroll
-                    for (int c = 0; c < 6; c++) s[c] = __builtin_fmaf(wh[c * 128 + co], v, s[c]);
+                    for (int e = 0; e < 8; e++) {
+                        const int r = 8 * s2 + e;
+                        float v = __builtin_fmaf(acc[r], kWUnscale, b3[acc_row(r, 0) + 4 * half]);
+                        v = v > 0.0f ? v : 0.0f;
+                        const _Float16 hh = (_Float16)v;
+                        xh8[e] = hh;
+                        xl8[e] = (_Float16)(v - (float)hh);
+                    }
+                    const half8 wh8 = *reinterpret_cast<const half8 *>(whp + s2 * 512);
+                    const half8 wl8 = *reinterpret_cast<const half8 *>(whp + s2 * 512 + 16);
+                    hd = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh8, xh8, hd, 0, 0, 0);
+                    hd = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl8, xh8, hd, 0, 0, 0);
+                    hd = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh8, xl8, hd, 0, 0, 0);
                 }
+                // rows 0-3 of the head tile sit in registers 0-3 of lanes 0-31, rows 4-5 in
+                // registers 0-1 of lanes 32-63
+                float *dst = hp + tile * 32 + j;
+                if (p < 0) return;                          // padding lane of the last tile
+                if (!half) {
 #pragma unroll
-                for (int c = 0; c < 6; c++) {
-                    const float o = __shfl_xor(s[c], 32);
-                    const float lo = half ? o : s[c], hi = half ? s[c] : o;
-                    if (!half) hp[c * G::NTP + tile * 32 + j] = lo + hi;
+                    for (int c = 0; c < 4; c++) dst[c * G::NTP] = hd[c];
+                } else {
+                    dst[4 * G::NTP] = hd[0];
+                    dst[5 * G::NTP] = hd[1];
                 }
-            });
+            }, &prof);
     }
     prof.mark(5);
     __syncthreads();
     prof.mark(6);
-    cnn_tail<G>(nw, lds, prof);
+    cnn16_tail<G>(nw, lds, tid, prof);
 }
 
 // One-time LDS set-up: the zero rows of the A2 images and the head weights.
@@ -271,7 +504,12 @@ __device__ inline void cnn16_prepare(const NetWeights &nw, float *lds)
     if (tid < G::RS_A2 / 16) *reinterpret_cast<half8 *>(ldb + G::A2H_OFF + G::NP * G::RS_A2 + tid * 16) = z8;
     if (tid >= 64 && tid < 64 + G::RS_A2 / 16)
         *reinterpret_cast<half8 *>(ldb + G::A2L_OFF + G::NP * G::RS_A2 + (tid - 64) * 16) = z8;
-    for (int idx = tid; idx < 6 * 128; idx += 256) lds[G::WH_OFF / 4 + idx] = nw.whead[idx];
+    reinterpret_cast<half8 *>(ldb + G::WH_OFF)[tid] = reinterpret_cast<const half8 *>(nw.whead16)[tid];
+    float *lb = lds + G::BIAS_OFF / 4;
+    if (tid < 32) lb[tid] = nw.bconv[0][tid];
+    else if (tid < 96) lb[tid] = nw.bconv[1][tid - 32];
+    else if (tid < 224) lb[tid] = nw.bconv[2][tid - 96];
+    else if (tid < 232) lb[tid] = tid < 230 ? nw.bhead[tid - 224] : 0.0f;
     __syncthreads();
 }
 

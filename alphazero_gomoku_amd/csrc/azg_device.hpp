@@ -8,6 +8,7 @@ namespace azg {
 constexpr int MAXW = 4;            // 64-bit words per colour (boards up to 16x16 = 256 cells)
 constexpr int MAXS = 256;
 constexpr int WAVE = 64;
+constexpr int kStampWords = 32 + 2 * 2048;   // diagnostic counters (see Prof)
 
 // Edge meta word: action (cell id) in the low 16 bits, number of children in the high 16.
 __host__ __device__ inline unsigned meta_pack(int act, int k) { return (unsigned)act | ((unsigned)k << 16); }
@@ -21,6 +22,8 @@ __host__ __device__ inline int meta_k(unsigned m) { return (int)(m >> 16); }
 struct NetWeights {
     const float *wconv[3];   // packed conv1..conv3 (float32 path)
     const void *w16[3];      // packed conv1..conv3 as split halves (azg_cnn16.hpp)
+    const void *wfc16[2];    // act_fc1 / val_fc1 as split halves in MFMA A-operand order (azg_cnn16.hpp)
+    const void *whead16;     // the two 1x1 head convolutions as split halves (azg_cnn16.hpp), 4 KB
     const float *bconv[3];   // biases [32],[64],[128]
     const float *whead;      // [6][128]: rows 0-3 act_conv1, rows 4-5 val_conv1
     const float *bhead;      // [6]
@@ -54,21 +57,45 @@ __device__ inline NetWeights opaque_weights(const NetWeights &w)
 {
     NetWeights o;
     for (int i = 0; i < 3; i++) { o.wconv[i] = opaque(w.wconv[i]); o.w16[i] = opaque((const char *)w.w16[i]); o.bconv[i] = opaque(w.bconv[i]); }
+    for (int i = 0; i < 2; i++) o.wfc16[i] = opaque((const char *)w.wfc16[i]);
+    o.whead16 = opaque((const char *)w.whead16);
     o.whead = opaque(w.whead); o.bhead = opaque(w.bhead); o.wpfc = opaque(w.wpfc); o.bpfc = opaque(w.bpfc);
     o.wvfc1 = opaque(w.wvfc1); o.bvfc1 = opaque(w.bvfc1); o.wvfc2 = opaque(w.wvfc2); o.bvfc2 = opaque(w.bvfc2);
     return o;
 }
 
-// Phase timer of the diagnostic build: thread 0 of workgroup 0 adds the cycles since its
+// Phase timer of the diagnostic build: thread 0 of every workgroup adds the cycles since its
 // previous mark to slot i.  Compiles to nothing in the normal build.
 struct Prof {
 #ifdef AZG_STAMPS
-    long long *out; long long last; bool on;
-    __device__ void start(long long *o) { out = o; on = o != nullptr && blockIdx.x == 0 && threadIdx.x == 0; last = __builtin_amdgcn_s_memtime(); }
-    __device__ void mark(int i) { if (on) { const long long now = __builtin_amdgcn_s_memtime(); out[i] += now - last; last = now; } }
+    // s_getreg operands: id | offset << 6 | (width - 1) << 11
+    static constexpr int GETREG_HW_ID = 4 | (0 << 6) | (31 << 11), GETREG_XCC_ID = 20 | (0 << 6) | (3 << 11);
+    long long *out; long long last, t0, r0; bool on;
+    unsigned acc[20];
+    __device__ void start(long long *o)
+    {
+        out = o; on = o != nullptr && threadIdx.x == 0;
+        for (int i = 0; i < 20; i++) acc[i] = 0;
+        last = t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime();
+    }
+    __device__ void mark(int i) { if (on) { const long long now = __builtin_amdgcn_s_memtime(); acc[i] += (unsigned)(now - last); last = now; } }
+    // slots 30 / 31: shader cycles and 100 MHz ticks of the whole loop (their ratio is the clock held)
+    __device__ void finish()
+    {
+        if (!on) return;
+        for (int i = 0; i < 20; i++) atomicAdd((unsigned long long *)&out[i], (unsigned long long)acc[i]);
+        atomicAdd((unsigned long long *)&out[30], (unsigned long long)(__builtin_amdgcn_s_memtime() - t0));
+        const unsigned long long rt = (unsigned long long)(__builtin_amdgcn_s_memrealtime() - r0);
+        atomicAdd((unsigned long long *)&out[31], rt);
+        if (blockIdx.x < 2048) {
+            out[32 + 2 * blockIdx.x] = (long long)rt;
+            out[33 + 2 * blockIdx.x] = ((long long)__builtin_amdgcn_s_getreg(GETREG_XCC_ID) << 32) | __builtin_amdgcn_s_getreg(GETREG_HW_ID);
+        }
+    }
 #else
     __device__ void start(long long *) {}
     __device__ void mark(int) {}
+    __device__ void finish() {}
 #endif
 };
 
@@ -101,7 +128,7 @@ struct DevState {
     int *s_count;                  // [B] samples recorded (= plies played by the engine)
     long long *game_id;            // [B]
     unsigned char *drained;        // [B]
-    long long *stamps;             // [32] cycle counters of a diagnostic build (-DAZG_STAMPS)
+    long long *stamps;             // [kStampWords] counters of a diagnostic build (-DAZG_STAMPS)
     NetWeights net;
 };
 

@@ -135,6 +135,7 @@ __global__ __launch_bounds__(256, (F16 && MODE == 0 && N <= 8) ? 2 : 1) void sea
         }
         prof.mark(10);
     }
+    prof.finish();
     if (active && lane == 0) st.evals[g] += n_eval;
 }
 

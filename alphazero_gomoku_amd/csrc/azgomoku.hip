@@ -3,6 +3,7 @@
 #include "../../include/azgomoku.h"
 
 #include <algorithm>
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -235,7 +236,7 @@ static int create_impl(azg_handle *h)
     if ((rc = dev_alloc(h, &st.s_pi, (size_t)B * S * S, false))) return rc;
     if ((rc = dev_alloc(h, &st.game_id, B))) return rc;
     if ((rc = dev_alloc(h, &st.drained, B))) return rc;
-    if ((rc = dev_alloc(h, &st.stamps, 32))) return rc;
+    if ((rc = dev_alloc(h, &st.stamps, kStampWords))) return rc;
     if ((rc = dev_alloc(h, &h->d_noise, (size_t)B * S))) return rc;
     if ((rc = dev_alloc(h, &h->d_u, B))) return rc;
     if ((rc = dev_alloc(h, &h->d_pi, (size_t)B * S))) return rc;
@@ -327,6 +328,48 @@ static void pack_conv16(const float *w, int cin, int cinp, int cout, _Float16 *o
             }
 }
 
+// Split-f16 image of a fully connected matrix W[O][K] (row-major) for azg_cnn16.hpp: per
+// (output tile of 32, k-step of 16) and lane, 8 high halves then 8 low halves of
+// W[o = tile*32 + (lane&31)][k = ks*16 + 8*(lane>>5) + j] * 2^8; rows >= O and columns >= K are zero.
+static void pack_fc16(const float *w, int O, int K, int otiles, int ksteps, _Float16 *out)
+{
+    for (int ot = 0; ot < otiles; ot++)
+        for (int ks = 0; ks < ksteps; ks++)
+            for (int lane = 0; lane < 64; lane++) {
+                const int o = ot * 32 + (lane & 31);
+                _Float16 *dst = out + (((size_t)ot * ksteps + ks) * 64 + lane) * 16;
+                for (int j = 0; j < 8; j++) {
+                    const int k = ks * 16 + 8 * (lane >> 5) + j;
+                    const float v = (o < O && k < K) ? w[(size_t)o * K + k] * kWScale : 0.0f;
+                    const _Float16 hi = (_Float16)v;
+                    dst[j] = hi;
+                    dst[8 + j] = (_Float16)(v - (float)hi);
+                }
+            }
+}
+
+// Split-f16 image of the two 1x1 head convolutions (rows 0-3 act_conv1, 4-5 val_conv1) for
+// azg_cnn16.hpp.  conv3's accumulators feed the head MFMA directly as its B operand, so the k
+// index follows the accumulator layout: entry ((wave*2 + s)*2 + kb)*8 + c holds, for j = 0..7,
+// W[c][co = wave*32 + acc_row(8*s + j, kb)] * 2^8 as 8 high halves then 8 low halves; rows 6, 7 are zero.
+static void pack_head16(const float *wh /*[6][128]*/, _Float16 *out)
+{
+    for (int wave = 0; wave < 4; wave++)
+        for (int s = 0; s < 2; s++)
+            for (int kb = 0; kb < 2; kb++)
+                for (int c = 0; c < 8; c++) {
+                    _Float16 *dst = out + ((((size_t)wave * 2 + s) * 2 + kb) * 8 + c) * 16;
+                    for (int j = 0; j < 8; j++) {
+                        const int r = 8 * s + j;
+                        const int co = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * kb;
+                        const float v = c < 6 ? wh[c * 128 + co] * kWScale : 0.0f;
+                        const _Float16 hi = (_Float16)v;
+                        dst[j] = hi;
+                        dst[8 + j] = (_Float16)(v - (float)hi);
+                    }
+                }
+}
+
 extern "C" int azg_set_weights(azg_handle *h, const float *const ptrs[16], int layout)
 {
     if (!h || !ptrs) return fail(h, AZG_EINVAL, "null argument");
@@ -368,6 +411,20 @@ extern "C" int azg_set_weights(azg_handle *h, const float *const ptrs[16], int l
     // split-f16 conv images: (cotiles * 9*CG k-steps * 64 lanes * 16 halves) / 2 floats
     const size_t psz16[3] = {(size_t)1 * 9 * 64 * 8, (size_t)2 * 18 * 64 * 8, (size_t)4 * 36 * 64 * 8};
     for (int i = 0; i < 3; i++) { off16[i] = total; total += al(psz16[i]); }
+    // split-f16 FC images: k-steps padded to a multiple of 4 (one quarter per wave)
+    const int otp = (S + 31) / 32, ksp = ((4 * S + 15) / 16 + 3) / 4 * 4, ksv = ((2 * S + 15) / 16 + 3) / 4 * 4;
+    const size_t offfc[2] = {total, total + al((size_t)otp * ksp * 64 * 8)};
+    total = offfc[1] + al((size_t)2 * ksv * 64 * 8);
+    const size_t offh16 = total;
+    total += 1024;                                           // 4 KB of head weights as halves
+    if (h->cfg.cnn_mode == AZG_CNN_F16X3) {
+        // halves hold w * 2^8: larger weights would overflow to infinity
+        for (int i : {0, 2, 4, 6, 8, 10, 12})
+            for (float v : t[i])
+                if (!(std::fabs(v) < 240.0f))
+                    return fail(h, AZG_EINVAL, "weight tensor %d holds |w| >= 240 (or NaN): out of range for the "
+                                "split-f16 convolutions, create the engine with AZG_CNN_F32", i);
+    }
     std::vector<float> host(total, 0.f);
     pack_conv(t[0].data(), 4, 32, &host[off[0]]);
     pack_conv(t[2].data(), 32, 64, &host[off[1]]);
@@ -375,12 +432,15 @@ extern "C" int azg_set_weights(azg_handle *h, const float *const ptrs[16], int l
     pack_conv16(t[0].data(), 4, 16, 32, reinterpret_cast<_Float16 *>(&host[off16[0]]));
     pack_conv16(t[2].data(), 32, 32, 64, reinterpret_cast<_Float16 *>(&host[off16[1]]));
     pack_conv16(t[4].data(), 64, 64, 128, reinterpret_cast<_Float16 *>(&host[off16[2]]));
+    pack_fc16(t[8].data(), S, 4 * S, otp, ksp, reinterpret_cast<_Float16 *>(&host[offfc[0]]));
+    pack_fc16(t[12].data(), 64, 2 * S, 2, ksv, reinterpret_cast<_Float16 *>(&host[offfc[1]]));
     std::copy(t[1].begin(), t[1].end(), &host[off[3]]);
     std::copy(t[3].begin(), t[3].end(), &host[off[4]]);
     std::copy(t[5].begin(), t[5].end(), &host[off[5]]);
     std::copy(t[6].begin(), t[6].end(), &host[off[6]]);             // act_conv1 rows 0-3
     std::copy(t[10].begin(), t[10].end(), &host[off[6] + 4 * 128]); // val_conv1 rows 4-5
     std::copy(t[7].begin(), t[7].end(), &host[off[7]]);
+    pack_head16(&host[off[6]], reinterpret_cast<_Float16 *>(&host[offh16]));
     std::copy(t[11].begin(), t[11].end(), &host[off[7] + 4]);
     for (int a = 0; a < S; a++)
         for (int k = 0; k < 4 * S; k++) host[off[8] + ((size_t)(k / 4) * S + a) * 4 + k % 4] = t[8][(size_t)a * 4 * S + k];
@@ -397,6 +457,8 @@ extern "C" int azg_set_weights(azg_handle *h, const float *const ptrs[16], int l
     const float *d = h->d_weights;
     nw.wconv[0] = d + off[0]; nw.wconv[1] = d + off[1]; nw.wconv[2] = d + off[2];
     nw.w16[0] = d + off16[0]; nw.w16[1] = d + off16[1]; nw.w16[2] = d + off16[2];
+    nw.wfc16[0] = d + offfc[0]; nw.wfc16[1] = d + offfc[1];
+    nw.whead16 = d + offh16;
     nw.bconv[0] = d + off[3]; nw.bconv[1] = d + off[4]; nw.bconv[2] = d + off[5];
     nw.whead = d + off[6]; nw.bhead = d + off[7];
     nw.wpfc = d + off[8]; nw.bpfc = d + off[9];
@@ -714,14 +776,15 @@ extern "C" int azg_board_step_batch(azg_handle *h, int n, uint64_t *stones, int3
     return AZG_OK;
 }
 
-// Diagnostic builds (-DAZG_STAMPS) only: cycle counters of workgroup 0's phases.
-extern "C" int azg_debug_stamps(azg_handle *h, long long out[32])
+// Diagnostic builds (-DAZG_STAMPS) only: 32 summed phase counters, then per workgroup of the
+// last search launch (loop time in 100 MHz ticks, hardware id) for the first 2048 workgroups.
+extern "C" int azg_debug_stamps(azg_handle *h, long long out[kStampWords])
 {
     if (!h || !out) return AZG_EINVAL;
     HIPCHK(h, hipSetDevice(h->cfg.device));
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    HIPCHK(h, hipMemcpy(out, h->st.stamps, 32 * sizeof(long long), hipMemcpyDeviceToHost));
-    HIPCHK(h, hipMemset(h->st.stamps, 0, 32 * sizeof(long long)));
+    HIPCHK(h, hipMemcpy(out, h->st.stamps, kStampWords * sizeof(long long), hipMemcpyDeviceToHost));
+    HIPCHK(h, hipMemset(h->st.stamps, 0, kStampWords * sizeof(long long)));
     return AZG_OK;
 }
 

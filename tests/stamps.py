@@ -9,19 +9,48 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 eng = az.SelfPlayEngine(n, 5, 400 if n == 8 else 200, B)
 eng.set_weights(helpers.make_params(n, seed=100 + n))
-eng.reset_games(seeds=np.arange(B, dtype=np.uint32))
-for _ in range(6):
-    eng.search(); eng.sample_and_advance(1.0, want_pi=False)
-out = (C.c_longlong * 32)()
+from alphazero_gomoku_amd.engine import SelfPlayRunner
+run = SelfPlayRunner(eng, temp=1.0, seed0=0, total=None, on_samples=None, device_samples=False)
+run.start()
+WARM = int(os.environ.get("WARM", "40"))        # steps before the measured ones (finished games are restarted)
+for _ in range(WARM):
+    run.step()
+NW = 32 + 2 * 2048
+out = (C.c_longlong * NW)()
 eng.L.azg_debug_stamps.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]
 eng.L.azg_debug_stamps(eng.h, out)
 eng.profile()
 for _ in range(4):
-    eng.search(); eng.sample_and_advance(1.0, want_pi=False)
+    run.step()
 eng.L.azg_debug_stamps(eng.h, out)
 l, ms, ev = eng.profile()
-names = ["select+end", "sync->cnn", "fill", "conv1", "conv2", "conv3+heads", "sync", "headsum", "fc", "softmax", "expand+backup"]
-tot = sum(out[:11])
-print("launches", l, "ms/launch", ms / l, "cycles/playout", tot / (4 * eng.n_playout))
+names = ["select+end", "sync->cnn", "fill", "conv1", "conv2", "conv3+heads", "sync", "headsum", "fc", "softmax", "expand+backup", "conv3 k-loop", "conv1 setup", "conv1 k-loop", "conv2 setup", "conv2 k-loop", "conv1 epilogue", "conv2 epilogue"]
+ngroups = (B + 1) // 2 if n <= 8 else B          # workgroups per launch
+raw = list(out)
+out = [v / ngroups for v in out]
+tot = sum(out[:20])
+print("launches", l, "ms/launch", ms / l, "cycles/playout", tot / (4 * eng.n_playout),
+      "clock GHz", out[30] / max(1, out[31]) * 0.1)
 for i, nm in enumerate(names):
     print("%-14s %8.0f cyc/playout  %5.1f%%" % (nm, out[i] / (4 * eng.n_playout), 100.0 * out[i] / tot))
+wg = np.array(raw[32:32 + 2 * ngroups], dtype=np.int64).reshape(-1, 2)
+ms_wg = wg[:, 0] * 1e-5
+xcc = (wg[:, 1] >> 32) & 0xF
+hw = wg[:, 1] & 0xFFFFFFFF
+cu = (hw >> 8) & 0xF
+se = (hw >> 13) & 0x7
+print("loop time per workgroup of the last launch, ms: mean %.3f  min %.3f  max %.3f" % (ms_wg.mean(), ms_wg.min(), ms_wg.max()))
+for x in range(8):
+    m = xcc == x
+    if m.any():
+        print("  xcc %d: %3d workgroups  mean %.3f  max %.3f" % (x, m.sum(), ms_wg[m].mean(), ms_wg[m].max()))
+key = xcc * 1000 + se * 32 + ((hw >> 12) & 1) * 16 + cu
+cnt = np.bincount(np.unique(key, return_counts=True)[1])
+print("workgroups per (xcc, se, cu):", {i: int(c) for i, c in enumerate(cnt) if c})
+order = np.argsort(key, kind="stable")
+pairs = ms_wg[order].reshape(-1, 2)
+pairs.sort(axis=1)
+print("per CU (two workgroups): faster mean %.3f, slower mean %.3f; slower - faster: mean %.3f max %.3f" % (
+    pairs[:, 0].mean(), pairs[:, 1].mean(), (pairs[:, 1] - pairs[:, 0]).mean(), (pairs[:, 1] - pairs[:, 0]).max()))
+print("histogram of workgroup loop times (ms):", np.histogram(ms_wg, bins=10)[0].tolist(), np.round(np.histogram(ms_wg, bins=10)[1], 2).tolist())
+print("histogram of the slower workgroup per CU:", np.histogram(pairs[:, 1], bins=8)[0].tolist(), np.round(np.histogram(pairs[:, 1], bins=8)[1], 2).tolist())
