@@ -46,8 +46,11 @@ struct Cnn16Geom {
     static constexpr int A2H_OFF = A1L_OFF + ROWS * RS_A1;
     static constexpr int A2L_OFF = A2H_OFF + ROWS * RS_A2;
     static constexpr int WH_OFF = A2L_OFF + ROWS * RS_A2;     // head weights as halves (4 KB, layout of pack_head16)
-    static constexpr int BIAS_OFF = WH_OFF + 4096;            // f32: conv1 [32], conv2 [64], conv3 [128], heads [6 + 2 pad]
-    static constexpr int END_BYTES = BIAS_OFF + (32 + 64 + 128 + 8) * 4;
+    // f32 constants: conv1 bias [32], conv2 [64], conv3 [128], heads [6 + 2 pad], val_fc1 bias [64],
+    // val_fc2 weights [64], val_fc2 bias [1 + 7 pad], act_fc1 bias [S padded to 8]
+    static constexpr int BIAS_OFF = WH_OFF + 4096;
+    static constexpr int B_HEAD = 224, B_VFC1 = 232, B_WVFC2 = 296, B_VFC2 = 360, B_PFC = 368;
+    static constexpr int END_BYTES = BIAS_OFF + (B_PFC + ((S + 7) & ~7)) * 4;
     static constexpr int END = (END_BYTES + 3) / 4;           // in floats, like CnnGeom::END
     // fully connected layers as MFMA GEMMs: D[output][leaf] = sum_k W[output][k] * x[k][leaf];
     // every wave takes a quarter of the k-steps of every output tile
@@ -103,9 +106,9 @@ __device__ inline void conv_preload(const half8 *wp, int wave, int lane, WRing<R
 // halves: 8 hi then 8 lo of W[co = cotile*32 + (lane&31)][ci = cg*16 + 8*(lane>>5) + j].
 // XLO = false skips the w_hi*x_lo term (exact inputs).  xh / xl: hi / lo image
 // ([NP rows + zero row][RS bytes]).  ring: filled by conv_preload for the same layer.
-template <class G, int CINP, int COUT, int RS, bool XLO, bool BPF, int RING, class Epi>
+template <class G, int CINP, int COUT, int RS, bool XLO, bool BPF, int RING, class Prep, class Epi>
 __device__ inline void conv3x3_f16(const half8 *wp, WRing<RING> &ring, const char *xh, const char *xl, int wave,
-                                   int lane, Epi epi, Prof *prof = nullptr, int slot = 11)
+                                   int lane, Prep prep, Epi epi, Prof *prof = nullptr, int slot = 11)
 {
     constexpr int CT = COUT / 32;
     constexpr int WPC = 4 / CT;
@@ -205,9 +208,13 @@ __device__ inline void conv3x3_f16(const half8 *wp, WRing<RING> &ring, const cha
         __builtin_amdgcn_sched_barrier(0);
     }
     if (prof) prof->mark(slot);
+    // prep() reads what every tile's epilogue needs from LDS once, before the first epilogue
+    // store (the compiler must assume a later read could alias such a store and would
+    // otherwise serialise read -> wait -> compute -> store per group of values)
+    const auto ctx = prep();
 #pragma unroll
     for (int i = 0; i < PT; i++)
-        if (sub * PT + i < G::NT) epi(i, sub * PT + i, acc[i], prow[i]);   // wave-uniform: epilogues may use MFMA
+        if (sub * PT + i < G::NT) epi(i, sub * PT + i, acc[i], prow[i], ctx);   // wave-uniform: epilogues may use MFMA
 }
 
 // Everything after conv3 for the split-f16 path: head outputs (bias + the four channel-tile
@@ -255,8 +262,38 @@ __device__ inline void cnn16_tail(const NetWeights &nw, float *lds, int tid, Pro
 
     // ---- head outputs, flattened [c][row][col] per head like the reference's view(-1, ...)
     {
-        const float *bh = lds + G::BIAS_OFF / 4 + 224;
+        const float *bh = lds + G::BIAS_OFF / 4 + G::B_HEAD;
         _Float16 *xb = reinterpret_cast<_Float16 *>(lds + G::X_OFF);
+        if constexpr (G::S % 4 == 0) {
+            // four consecutive features (same head channel, consecutive cells) per thread
+            for (int e4 = tid; e4 < G::T * (G::KPP + G::KPV) / 4; e4 += 256) {
+                const int e = 4 * e4;
+                const bool pol = e < G::T * G::KPP;
+                const int e2 = pol ? e : e - G::T * G::KPP;
+                const int kp = pol ? G::KPP : G::KPV;
+                const int leaf = e2 / kp, k = e2 - leaf * kp;
+                f32x4 s = {0.f, 0.f, 0.f, 0.f};
+                if (k < (pol ? 4 : 2) * G::S) {
+                    const int cc = k / G::S, cell = k - cc * G::S;
+                    const int c = pol ? cc : 4 + cc, p = leaf * G::S + cell;
+                    const float *pp = lds + G::HP_OFF + c * G::NTP + p;
+                    const f32x4 p0 = *reinterpret_cast<const f32x4 *>(pp), p1 = *reinterpret_cast<const f32x4 *>(pp + 6 * G::NTP);
+                    const f32x4 p2 = *reinterpret_cast<const f32x4 *>(pp + 12 * G::NTP), p3 = *reinterpret_cast<const f32x4 *>(pp + 18 * G::NTP);
+                    const float b = bh[c];
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const float v = __builtin_fmaf((p0[i] + p1[i]) + (p2[i] + p3[i]), kWUnscale, b);
+                        s[i] = v > 0.0f ? v : 0.0f;
+                    }
+                }
+                half4 h, l;
+#pragma unroll
+                for (int i = 0; i < 4; i++) { h[i] = (_Float16)s[i]; l[i] = (_Float16)(s[i] - (float)h[i]); }
+                _Float16 *dst = xb + (pol ? 0 : 2 * G::T * G::KPP) + leaf * kp + k;
+                *reinterpret_cast<half4 *>(dst) = h;
+                *reinterpret_cast<half4 *>(dst + G::T * kp) = l;
+            }
+        } else {
         for (int e = tid; e < G::T * (G::KPP + G::KPV); e += 256) {
             const bool pol = e < G::T * G::KPP;
             const int e2 = pol ? e : e - G::T * G::KPP;
@@ -274,6 +311,7 @@ __device__ inline void cnn16_tail(const NetWeights &nw, float *lds, int tid, Pro
             _Float16 *dst = xb + (pol ? 0 : 2 * G::T * G::KPP) + leaf * kp + k;
             dst[0] = hi;
             dst[G::T * kp] = (_Float16)(s - (float)hi);
+        }
         }
     }
     __syncthreads();
@@ -304,17 +342,19 @@ __device__ inline void cnn16_tail(const NetWeights &nw, float *lds, int tid, Pro
             }
             const half8 wa = ah[u % RING], wl = al[u % RING];
             if (u + RING < NU) { const gptr<half8> s = wsrc(u + RING); ah[u % RING] = s[0]; al[u % RING] = s[1]; }
-            acc[q.tile] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa, xh, acc[q.tile], 0, 0, 0);
-            acc[q.tile] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, xh, acc[q.tile], 0, 0, 0);
-            acc[q.tile] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa, xl, acc[q.tile], 0, 0, 0);
-            if (q.last && n < G::T) {
+            // x is the A operand (row = leaf) and W the B operand (column = output), so a
+            // lane of the lower half-wave ends up with one output's value for every leaf in
+            // accumulator registers 0 .. T-1
+            acc[q.tile] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, wa, acc[q.tile], 0, 0, 0);
+            acc[q.tile] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, wl, acc[q.tile], 0, 0, 0);
+            acc[q.tile] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xl, wa, acc[q.tile], 0, 0, 0);
+            if (q.last && half == 0) {
 #pragma unroll
-                for (int i = 0; i < q.ntile; i++)
+                for (int i = 0; i < q.ntile; i++) {
+                    const int o = (q.fc ? G::OTP * 32 : q.grp * G::OC * 32) + i * 32 + n;
 #pragma unroll
-                    for (int r = 0; r < 16; r++) {
-                        const int o = (q.fc ? G::OTP * 32 : q.grp * G::OC * 32) + i * 32 + acc_row(r, half);
-                        lds[G::PART_OFF + (wave * G::NOUT + o) * G::T + n] = acc[i][r];
-                    }
+                    for (int t = 0; t < G::T; t++) lds[G::PART_OFF + (wave * G::NOUT + o) * G::T + t] = acc[i][t];
+                }
             }
         }
     }
@@ -324,6 +364,7 @@ __device__ inline void cnn16_tail(const NetWeights &nw, float *lds, int tid, Pro
     // ---- softmax over the S logits and the scalar value, one wave per position
     if (wave < G::T) {
         const int leaf = wave;
+        const float *lb = lds + G::BIAS_OFF / 4;
         auto fc_out = [&](int o, float bias) {
             const float *pp = lds + G::PART_OFF + o * G::T + leaf;
             const float s = (pp[0] + pp[G::NOUT * G::T]) + (pp[2 * G::NOUT * G::T] + pp[3 * G::NOUT * G::T]);
@@ -335,7 +376,7 @@ __device__ inline void cnn16_tail(const NetWeights &nw, float *lds, int tid, Pro
 #pragma unroll
         for (int i = 0; i < PER; i++) {
             const int a = lane + 64 * i;
-            x[i] = a < G::S ? fc_out(a, nw.bpfc[a]) : -3.0e38f;
+            x[i] = a < G::S ? fc_out(a, lb[G::B_PFC + a]) : -3.0e38f;
             mx = fmaxf(mx, x[i]);
         }
 #pragma unroll
@@ -354,21 +395,22 @@ __device__ inline void cnn16_tail(const NetWeights &nw, float *lds, int tid, Pro
             const int a = lane + 64 * i;
             if (a < G::S) lds[G::LG_OFF + leaf * G::S + a] = expf((x[i] - mx) - lse);
         }
-        float hdn = fc_out(G::OTP * 32 + lane, nw.bvfc1[lane]);
+        float hdn = fc_out(G::OTP * 32 + lane, lb[G::B_VFC1 + lane]);
         hdn = hdn > 0.0f ? hdn : 0.0f;
-        float v = hdn * nw.wvfc2[lane];
+        float v = hdn * lb[G::B_WVFC2 + lane];
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
-        if (lane == 0) lds[G::VAL_OFF + leaf] = tanhf(v + nw.bvfc2[0]);
+        if (lane == 0) lds[G::VAL_OFF + leaf] = tanhf(v + lb[G::B_VFC2]);
     }
     __syncthreads();
     prof.mark(9);
 }
 
-// Full forward; interface as cnn_forward (azg_cnn.hpp): results at lds[LG_OFF..] / lds[VAL_OFF..]
-// (float offsets).  Needs cnn16_prepare once per workgroup.
+// Full forward; results at lds[LG_OFF..] / lds[VAL_OFF..] (float offsets) as with cnn_forward
+// (azg_cnn.hpp), but `input(leaf, row, col, out[4])` supplies the four planes of a cell at once.  Needs cnn16_prepare once per workgroup.
 template <class G, class InputFn>
-__device__ inline void cnn16_forward(const NetWeights &nw_in, float *lds, InputFn input, Prof &prof)
+__device__ inline void cnn16_forward(const NetWeights &nw_in, float *lds, InputFn input, Prof &prof,
+                                     const MatrixGate &gate)
 {
     const NetWeights nw = opaque_weights(nw_in);
     char *ldb = reinterpret_cast<char *>(lds);
@@ -395,9 +437,11 @@ __device__ inline void cnn16_forward(const NetWeights &nw_in, float *lds, InputF
     for (int p = tid; p < G::NP; p += 256) {
         const int leaf = p / G::S, cell = p - leaf * G::S;
         const int row = cell / G::N, col = cell - row * G::N;
+        float pl[4];
+        input(leaf, row, col, pl);
         half8 v0 = z8;
 #pragma unroll
-        for (int ch = 0; ch < 4; ch++) v0[ch] = (_Float16)input(leaf, ch, row, col);
+        for (int ch = 0; ch < 4; ch++) v0[ch] = (_Float16)pl[ch];
         *reinterpret_cast<half8 *>(ldb + G::IN_OFF + p * G::RS_IN) = v0;
         *reinterpret_cast<half8 *>(ldb + G::IN_OFF + p * G::RS_IN + 16) = z8;
     }
@@ -410,16 +454,24 @@ __device__ inline void cnn16_forward(const NetWeights &nw_in, float *lds, InputF
     prof.mark(2);
 
     // epilogue of conv1/conv2: scale back, bias, ReLU, split into halves, store [pos][channel]
-    auto store_split = [&](const float *bias, int cobase, char *oh, char *ol, int rs) {
-        return [=](int, int, const f32x16 &acc, int p) {
+    struct Bias16 { f32x4 b[4]; };
+    auto load_bias = [&](const float *bias, int cobase) {
+        return [=]() {
+            Bias16 c;
+#pragma unroll
+            for (int g = 0; g < 4; g++) c.b[g] = *reinterpret_cast<const f32x4 *>(bias + cobase + 8 * g + 4 * half);
+            return c;
+        };
+    };
+    auto store_split = [&](int cobase, char *oh, char *ol, int rs) {
+        return [=](int, int, const f32x16 &acc, int p, const Bias16 &c) {
             if (p < 0) return;                              // padding lane of the last tile
 #pragma unroll
             for (int g = 0; g < 4; g++) {
                 half4 h, l;
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
-                    const int co = cobase + 8 * g + 4 * half + e;
-                    float v = __builtin_fmaf(acc[4 * g + e], kWUnscale, bias[co]);
+                    float v = __builtin_fmaf(acc[4 * g + e], kWUnscale, c.b[g][e]);
                     v = v > 0.0f ? v : 0.0f;
                     const _Float16 hh = (_Float16)v;
                     h[e] = hh;
@@ -433,14 +485,16 @@ __device__ inline void cnn16_forward(const NetWeights &nw_in, float *lds, InputF
     };
     conv_preload<32, 64, R2>(w2, wave, lane, ring2);
     conv3x3_f16<G, 16, 32, G::RS_IN, false, G::BPF, R1>(w1, ring1, ldb + G::IN_OFF, ldb + G::IN_OFF, wave, lane,
-                                                store_split(lbias, 0, ldb + G::A1H_OFF, ldb + G::A1L_OFF, G::RS_A1), &prof, 13);
+                                                load_bias(lbias, 0), store_split(0, ldb + G::A1H_OFF, ldb + G::A1L_OFF, G::RS_A1), &prof, 13);
     prof.mark(16);
+    if (tid == 0) gate.acquire();
     __syncthreads();
     prof.mark(3);
     conv_preload<64, 128, R3>(w3, wave, lane, ring3);
     conv3x3_f16<G, 32, 64, G::RS_A1, true, G::BPF, R2>(w2, ring2, ldb + G::A1H_OFF, ldb + G::A1L_OFF, wave, lane,
-                                               store_split(lbias + 32, (wave % 2) * 32, ldb + G::A2H_OFF,
-                                                           ldb + G::A2L_OFF, G::RS_A2), &prof, 15);
+                                               load_bias(lbias + 32, (wave % 2) * 32),
+                                               store_split((wave % 2) * 32, ldb + G::A2H_OFF, ldb + G::A2L_OFF, G::RS_A2),
+                                               &prof, 15);
     prof.mark(17);
     __syncthreads();
     prof.mark(4);
@@ -451,10 +505,22 @@ __device__ inline void cnn16_forward(const NetWeights &nw_in, float *lds, InputF
     //      the head weights are packed to match).  The four waves' partial sums meet in LDS.
     {
         const float *b3 = lbias + 96 + wave * 32;
+        struct Head16 { f32x4 b[4]; half8 wh[2], wl[2]; };
         float *hp = lds + G::HP_OFF + wave * 6 * G::NTP;
         const char *whp = ldb + G::WH_OFF + ((wave * 4 + half) * 8 + (j < 8 ? j : 7)) * 32;
         conv3x3_f16<G, 64, 128, G::RS_A2, true, G::BPF, R3>(w3, ring3, ldb + G::A2H_OFF, ldb + G::A2L_OFF, wave, lane,
-            [=](int, int tile, const f32x16 &acc, int p) {
+            [=]() {
+                Head16 c;
+#pragma unroll
+                for (int g = 0; g < 4; g++) c.b[g] = *reinterpret_cast<const f32x4 *>(b3 + 8 * g + 4 * half);
+#pragma unroll
+                for (int s2 = 0; s2 < 2; s2++) {
+                    c.wh[s2] = *reinterpret_cast<const half8 *>(whp + s2 * 512);
+                    c.wl[s2] = *reinterpret_cast<const half8 *>(whp + s2 * 512 + 16);
+                }
+                return c;
+            },
+            [=](int, int tile, const f32x16 &acc, int p, const Head16 &c) {
                 const f32x16 zacc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
                 f32x16 hd = zacc;
 #pragma unroll
@@ -463,17 +529,15 @@ __device__ inline void cnn16_forward(const NetWeights &nw_in, float *lds, InputF
 #pragma unroll
                     for (int e = 0; e < 8; e++) {
                         const int r = 8 * s2 + e;
-                        float v = __builtin_fmaf(acc[r], kWUnscale, b3[acc_row(r, 0) + 4 * half]);
+                        float v = __builtin_fmaf(acc[r], kWUnscale, c.b[r >> 2][r & 3]);
                         v = v > 0.0f ? v : 0.0f;
                         const _Float16 hh = (_Float16)v;
                         xh8[e] = hh;
                         xl8[e] = (_Float16)(v - (float)hh);
                     }
-                    const half8 wh8 = *reinterpret_cast<const half8 *>(whp + s2 * 512);
-                    const half8 wl8 = *reinterpret_cast<const half8 *>(whp + s2 * 512 + 16);
-                    hd = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh8, xh8, hd, 0, 0, 0);
-                    hd = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl8, xh8, hd, 0, 0, 0);
-                    hd = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh8, xl8, hd, 0, 0, 0);
+                    hd = __builtin_amdgcn_mfma_f32_32x32x16_f16(c.wh[s2], xh8, hd, 0, 0, 0);
+                    hd = __builtin_amdgcn_mfma_f32_32x32x16_f16(c.wl[s2], xh8, hd, 0, 0, 0);
+                    hd = __builtin_amdgcn_mfma_f32_32x32x16_f16(c.wh[s2], xl8, hd, 0, 0, 0);
                 }
                 // rows 0-3 of the head tile sit in registers 0-3 of lanes 0-31, rows 4-5 in
                 // registers 0-1 of lanes 32-63
@@ -490,6 +554,7 @@ __device__ inline void cnn16_forward(const NetWeights &nw_in, float *lds, InputF
     }
     prof.mark(5);
     __syncthreads();
+    if (tid == 0) gate.release();
     prof.mark(6);
     cnn16_tail<G>(nw, lds, tid, prof);
 }
@@ -510,6 +575,9 @@ __device__ inline void cnn16_prepare(const NetWeights &nw, float *lds)
     else if (tid < 96) lb[tid] = nw.bconv[1][tid - 32];
     else if (tid < 224) lb[tid] = nw.bconv[2][tid - 96];
     else if (tid < 232) lb[tid] = tid < 230 ? nw.bhead[tid - 224] : 0.0f;
+    if (tid < 64) { lb[G::B_VFC1 + tid] = nw.bvfc1[tid]; lb[G::B_WVFC2 + tid] = nw.wvfc2[tid]; }
+    if (tid == 64) lb[G::B_VFC2] = nw.bvfc2[0];
+    for (int a = tid; a < G::S; a += 256) lb[G::B_PFC + a] = nw.bpfc[a];
     __syncthreads();
 }
 

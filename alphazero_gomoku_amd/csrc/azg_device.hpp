@@ -9,6 +9,7 @@ constexpr int MAXW = 4;            // 64-bit words per colour (boards up to 16x1
 constexpr int MAXS = 256;
 constexpr int WAVE = 64;
 constexpr int kStampWords = 32 + 2 * 2048;   // diagnostic counters (see Prof)
+constexpr int kGateWords = 16 * 256;          // (XCC id, SE, SH, CU) -> gate word
 
 // Edge meta word: action (cell id) in the low 16 bits, number of children in the high 16.
 __host__ __device__ inline unsigned meta_pack(int act, int k) { return (unsigned)act | ((unsigned)k << 16); }
@@ -63,6 +64,38 @@ __device__ inline NetWeights opaque_weights(const NetWeights &w)
     o.wvfc1 = opaque(w.wvfc1); o.bvfc1 = opaque(w.bvfc1); o.wvfc2 = opaque(w.wvfc2); o.bvfc2 = opaque(w.bvfc2);
     return o;
 }
+
+// Two workgroups share a compute unit and its matrix pipes.  Matrix instructions of two
+// waves on one SIMD simply queue behind each other, so the pair gains only while one
+// workgroup's convolutions overlap the other's tree / softmax / load phases.  The gate makes
+// that the steady state: a workgroup takes its CU's gate before the dense convolution phase
+// and gives it back after, so the partner's dense phase starts when this one ends and the two
+// fall into opposite phase.  The gate is advisory: the wait is bounded and results never
+// depend on it (a workgroup that gives up just runs its convolutions beside the partner's).
+struct MatrixGate {
+    int *word;
+    __device__ void init(int *table)
+    {
+        // HW_REG_HW_ID bits: CU 11:8, SH 12, SE 15:13; HW_REG_XCC_ID bits 3:0
+        const unsigned hw = __builtin_amdgcn_s_getreg(4 | (8 << 6) | (7 << 11));
+        const unsigned xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11));
+        word = table ? table + ((xcc & 15u) * 256u + (hw & 255u)) : nullptr;
+    }
+    // thread 0 of the workgroup, followed by a workgroup barrier
+    __device__ void acquire() const
+    {
+        if (!word) return;
+        for (int tries = 0; tries < 2000; tries++) {
+            if (atomicCAS(word, 0, 1) == 0) return;
+            __builtin_amdgcn_s_sleep(16);
+        }
+    }
+    // thread 0 of the workgroup, after a workgroup barrier
+    __device__ void release() const
+    {
+        if (word) __hip_atomic_store(word, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+};
 
 // Phase timer of the diagnostic build: thread 0 of every workgroup adds the cycles since its
 // previous mark to slot i.  Compiles to nothing in the normal build.
@@ -128,6 +161,7 @@ struct DevState {
     int *s_count;                  // [B] samples recorded (= plies played by the engine)
     long long *game_id;            // [B]
     unsigned char *drained;        // [B]
+    int *cu_gate;                  // [kGateWords] one matrix-pipe gate per compute unit (see MatrixGate)
     long long *stamps;             // [kStampWords] counters of a diagnostic build (-DAZG_STAMPS)
     NetWeights net;
 };

@@ -21,10 +21,18 @@ template <int N, int T, bool F16>
 struct GeomPick { using type = typename std::conditional<F16, Cnn16Geom<N, T>, CnnGeom<N, T>>::type; };
 
 template <class G, bool F16, class InputFn>
-__device__ inline void net_forward(const NetWeights &nw, float *smem, InputFn input, Prof &prof)
+__device__ inline void net_forward(const NetWeights &nw, float *smem, InputFn input, Prof &prof,
+                                   const MatrixGate &gate)
 {
-    if constexpr (F16) cnn16_forward<G>(nw, smem, input, prof);
-    else cnn_forward<G>(nw, smem, input, prof);
+    if constexpr (F16) {
+        cnn16_forward<G>(nw, smem, input, prof, gate);
+    } else {
+        cnn_forward<G>(nw, smem, [&](int leaf, int pl, int row, int col) -> float {
+            float o[4];
+            input(leaf, row, col, o);
+            return o[pl];
+        }, prof);
+    }
 }
 
 template <class G, bool F16>
@@ -73,6 +81,8 @@ __global__ __launch_bounds__(256, (F16 && MODE == 0 && N <= 8) ? 2 : 1) void sea
     if (active && lane == 0) gl->arena = st.cur[g];
     wave_sync();
     long long n_eval = 0;
+    MatrixGate gate;
+    gate.init((F16 && MODE == 0 && N <= 8) ? st.cu_gate : nullptr);
     Prof prof;
     prof.start(st.stamps);
 
@@ -94,12 +104,10 @@ __global__ __launch_bounds__(256, (F16 && MODE == 0 && N <= 8) ? 2 : 1) void sea
 #pragma unroll
             for (int t = 0; t < T; t++) any |= gls[t].live && gls[t].need_eval;
             if (any) {
-                net_forward<G, F16>(st.net, smem, [&](int leaf, int pl, int row, int col) -> float {
+                net_forward<G, F16>(st.net, smem, [&](int leaf, int row, int col, float *out) {
                     const GameLds *q = &gls[leaf];
-                    if (!q->live) return 0.0f;
-                    return plane_value(q->leaf_bb, N, q->leaf_ply, q->leaf_last,
-                                       player_at(q->first_player, q->leaf_ply), pl, row, col);
-                }, prof);
+                    planes_at(q->leaf_bb, N, q->leaf_ply, q->leaf_last, q->first_player, q->live != 0, row, col, out);
+                }, prof, gate);
             } else {
                 __syncthreads();
             }
@@ -151,10 +159,12 @@ __global__ __launch_bounds__(256) void eval_kernel(NetWeights nw, const float *s
     net_prepare<G, F16>(nw, smem);
     Prof prof;
     prof.start(nullptr);
-    net_forward<G, F16>(nw, smem, [&](int leaf, int pl, int row, int col) -> float {
+    net_forward<G, F16>(nw, smem, [&](int leaf, int row, int col, float *out) {
         const int i = n0 + leaf;
-        return i < n ? states[((size_t)i * 4 + pl) * G::S + row * N + col] : 0.0f;
-    }, prof);
+#pragma unroll
+        for (int pl = 0; pl < 4; pl++)
+            out[pl] = i < n ? states[((size_t)i * 4 + pl) * G::S + row * N + col] : 0.0f;
+    }, prof, MatrixGate{nullptr});
     for (int idx = threadIdx.x; idx < T * G::S; idx += 256) {
         const int leaf = idx / G::S;
         if (n0 + leaf < n) probs[(size_t)n0 * G::S + idx] = smem[G::LG_OFF + idx];

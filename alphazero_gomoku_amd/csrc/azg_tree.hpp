@@ -268,4 +268,20 @@ __device__ inline float plane_value(const u64 (*bb)[MAXW], int N, int ply, int l
     return (ply & 1) ? 0.0f : 1.0f;
 }
 
+// All four planes of one cell (same layout); `live` false gives zeros.  Every LDS word is
+// read once and unconditionally, so the reads go out together.
+__device__ inline void planes_at(const u64 (*bb)[MAXW], int N, int ply, int last, int first_player, bool live,
+                                 int row, int col, float *out)
+{
+    const int cell = (N - 1 - row) * N + col;
+    const u64 s1 = bb[0][cell >> 6], s2 = bb[1][cell >> 6];
+    const bool first_to_move = ((ply & 1) == 0) == (first_player == 1);      // player 1 is to move
+    const u64 mine = first_to_move ? s1 : s2, theirs = first_to_move ? s2 : s1;
+    const float on = live ? 1.0f : 0.0f;
+    out[0] = ((mine >> (cell & 63)) & 1ULL) ? on : 0.0f;
+    out[1] = ((theirs >> (cell & 63)) & 1ULL) ? on : 0.0f;
+    out[2] = (ply > 0 && cell == last) ? on : 0.0f;
+    out[3] = (ply & 1) ? 0.0f : on;
+}
+
 }  // namespace azg
