@@ -115,7 +115,6 @@ __device__ inline void conv3x3_f16(const half8 *wp, WRing<RING> &ring, const cha
     constexpr int PT = (G::NT + WPC - 1) / WPC;
     constexpr int CG = CINP / 16;
     constexpr int KS = 9 * CG;
-    const int cot = wave % CT;
     const int sub = wave / CT;
     const int half = lane >> 5;
     const int j = lane & 31;

@@ -72,14 +72,18 @@ __device__ inline NetWeights opaque_weights(const NetWeights &w)
 // and gives it back after, so the partner's dense phase starts when this one ends and the two
 // fall into opposite phase.  The gate is advisory: the wait is bounded and results never
 // depend on it (a workgroup that gives up just runs its convolutions beside the partner's).
+// The table is shared by every engine of the process on a device, so workgroups of two
+// engines that run concurrently on separate streams pair up the same way.
+__device__ int g_matrix_gate[kGateWords];
+
 struct MatrixGate {
     int *word;
-    __device__ void init(int *table)
+    __device__ void init(bool enabled)
     {
         // HW_REG_HW_ID bits: CU 11:8, SH 12, SE 15:13; HW_REG_XCC_ID bits 3:0
         const unsigned hw = __builtin_amdgcn_s_getreg(4 | (8 << 6) | (7 << 11));
         const unsigned xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11));
-        word = table ? table + ((xcc & 15u) * 256u + (hw & 255u)) : nullptr;
+        word = enabled ? g_matrix_gate + ((xcc & 15u) * 256u + (hw & 255u)) : nullptr;
     }
     // thread 0 of the workgroup, followed by a workgroup barrier
     __device__ void acquire() const
@@ -161,7 +165,6 @@ struct DevState {
     int *s_count;                  // [B] samples recorded (= plies played by the engine)
     long long *game_id;            // [B]
     unsigned char *drained;        // [B]
-    int *cu_gate;                  // [kGateWords] one matrix-pipe gate per compute unit (see MatrixGate)
     long long *stamps;             // [kStampWords] counters of a diagnostic build (-DAZG_STAMPS)
     NetWeights net;
 };

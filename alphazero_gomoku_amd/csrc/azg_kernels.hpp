@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256, (F16 && MODE == 0 && N <= 8) ? 2 : 1) void sea
     wave_sync();
     long long n_eval = 0;
     MatrixGate gate;
-    gate.init((F16 && MODE == 0 && N <= 8) ? st.cu_gate : nullptr);
+    gate.init(F16 && MODE == 0 && N <= 8);
     Prof prof;
     prof.start(st.stamps);
 

@@ -237,7 +237,6 @@ static int create_impl(azg_handle *h)
     if ((rc = dev_alloc(h, &st.game_id, B))) return rc;
     if ((rc = dev_alloc(h, &st.drained, B))) return rc;
     if ((rc = dev_alloc(h, &st.stamps, kStampWords))) return rc;
-    if ((rc = dev_alloc(h, &st.cu_gate, kGateWords))) return rc;
     if ((rc = dev_alloc(h, &h->d_noise, (size_t)B * S))) return rc;
     if ((rc = dev_alloc(h, &h->d_u, B))) return rc;
     if ((rc = dev_alloc(h, &h->d_pi, (size_t)B * S))) return rc;
@@ -537,7 +536,6 @@ extern "C" int azg_search(azg_handle *h)
         h->ev_pool.emplace_back(a, b);
     }
     auto &ev = h->ev_pool[h->ev_pending];
-    HIPCHK(h, hipMemsetAsync(h->st.cu_gate, 0, kGateWords * sizeof(int), h->stream));   // all gates open
     HIPCHK(h, hipEventRecord(ev.first, h->stream));
     hipLaunchKernelGGL(sl.fn, dim3(grid), dim3(256), sl.lds, h->stream, h->st);
     HIPCHK(h, hipGetLastError());

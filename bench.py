@@ -23,6 +23,9 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 FLOP_PER_EVAL = {6: 6.79e6, 8: 12.09e6, 15: 42.80e6}    # 188416*S + 8*S*S + 128, 2 flop / MAC
 PEAK_TFLOPS = {"f16x3": 2500.0, "f32": 157.3}            # dense MFMA peaks of MI355X: f16 inputs / f32 inputs
+# HBM bytes per search launch from rocprofv3 PMC passes (FETCH_SIZE + WRITE_SIZE, separate runs,
+# profiles/r1_d_pmc_search_kernel.json); only valid for the default workload and build
+PMC_TRAFFIC_BYTES = {("f16x3", 8, 400, 1024): (271795.3 + 580881.1) * 1024.0}
 
 
 def random_init_params(n, device):
@@ -154,7 +157,10 @@ def main():
             "playouts_per_s": evals / dt, "samples_gathered": gathered,
             "roofline": {"bound": "mfma", "kernel": "search_kernel (fused select + leaf CNN + expand + backup)",
                          "achieved": achieved, "peak": PEAK_TFLOPS[args.cnn], "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_TFLOPS[args.cnn], "traffic": None,
+                         "frac": achieved / PEAK_TFLOPS[args.cnn],
+                         "traffic": PMC_TRAFFIC_BYTES.get((args.cnn, n, args.playouts, args.games)),
+                         "traffic_note": "HBM bytes per launch, FETCH_SIZE + WRITE_SIZE of a separate rocprofv3 --pmc run "
+                                         "(tree arrays; 4-8 B per lane accesses, no width correction applied)",
                          "note": "achieved counts the ALGORITHMIC flops of the leaf CNN (12.09 MFLOP per evaluation at 8x8); "
                                  "the f16x3 path issues ~2.9x that many MFMA flops",
                          "launches": launches, "avg_launch_ms": kernel_ms / launches if launches else None,
