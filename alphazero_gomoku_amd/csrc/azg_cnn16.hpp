@@ -62,11 +62,11 @@ struct Cnn16Geom {
     static constexpr int NOUT = OTP * 32 + 64;
     static_assert(OTP % OC == 0, "act_fc1 output tiles must split evenly into accumulator groups");
     // f32 scratch that aliases IN + A1 once conv2 has consumed them (float offsets)
-    static constexpr int HP_OFF = 0;                          // head partials [4 waves][6][NTP]
+    static constexpr int HP_OFF = 0;                          // head partials [4 waves][8][NTP] (rows 6, 7 unused)
     static constexpr int PART_OFF = 0;                        // FC partials [4 waves][NOUT][T] (HP is dead by then)
     static constexpr int LG_OFF = PART_OFF + 4 * NOUT * T_;   // probabilities [T][S]
     static constexpr int VAL_OFF = LG_OFF + T_ * S;           // values [T]
-    static constexpr int X_OFF = HP_OFF + 24 * NTP;           // head outputs as halves: hi [T][KPP], lo [T][KPP], hi [T][KPV], lo [T][KPV]
+    static constexpr int X_OFF = HP_OFF + 32 * NTP;           // head outputs as halves: hi [T][KPP], lo [T][KPP], hi [T][KPV], lo [T][KPV]
     static constexpr int X_END = X_OFF + T_ * (KPP + KPV);
     static_assert(VAL_OFF + T_ <= X_OFF, "FC partials and results must fit in the head-partial region");
     static_assert(X_END * 4 <= A2H_OFF, "scratch does not fit under IN+A1");
@@ -276,8 +276,8 @@ __device__ inline void cnn16_tail(const NetWeights &nw, float *lds, int tid, Pro
                     const int cc = k / G::S, cell = k - cc * G::S;
                     const int c = pol ? cc : 4 + cc, p = leaf * G::S + cell;
                     const float *pp = lds + G::HP_OFF + c * G::NTP + p;
-                    const f32x4 p0 = *reinterpret_cast<const f32x4 *>(pp), p1 = *reinterpret_cast<const f32x4 *>(pp + 6 * G::NTP);
-                    const f32x4 p2 = *reinterpret_cast<const f32x4 *>(pp + 12 * G::NTP), p3 = *reinterpret_cast<const f32x4 *>(pp + 18 * G::NTP);
+                    const f32x4 p0 = *reinterpret_cast<const f32x4 *>(pp), p1 = *reinterpret_cast<const f32x4 *>(pp + 8 * G::NTP);
+                    const f32x4 p2 = *reinterpret_cast<const f32x4 *>(pp + 16 * G::NTP), p3 = *reinterpret_cast<const f32x4 *>(pp + 24 * G::NTP);
                     const float b = bh[c];
 #pragma unroll
                     for (int i = 0; i < 4; i++) {
@@ -303,7 +303,7 @@ __device__ inline void cnn16_tail(const NetWeights &nw, float *lds, int tid, Pro
                 const int cc = k / G::S, cell = k - cc * G::S;
                 const int c = pol ? cc : 4 + cc, p = leaf * G::S + cell;
                 const float *pp = lds + G::HP_OFF + c * G::NTP + p;
-                s = __builtin_fmaf((pp[0] + pp[6 * G::NTP]) + (pp[12 * G::NTP] + pp[18 * G::NTP]), kWUnscale, bh[c]);
+                s = __builtin_fmaf((pp[0] + pp[8 * G::NTP]) + (pp[16 * G::NTP] + pp[24 * G::NTP]), kWUnscale, bh[c]);
                 s = s > 0.0f ? s : 0.0f;
             }
             const _Float16 hi = (_Float16)s;
@@ -418,6 +418,7 @@ __device__ inline void cnn16_forward(const NetWeights &nw_in, float *lds, InputF
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    __builtin_assume(wave >= 0 && wave < 4);               // 256-thread workgroups: lets tile-validity tests fold
     const int half = lane >> 5, j = lane & 31;
     const half8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
 
@@ -464,7 +465,7 @@ __device__ inline void cnn16_forward(const NetWeights &nw_in, float *lds, InputF
     };
     auto store_split = [&](int cobase, char *oh, char *ol, int rs) {
         return [=](int, int, const f32x16 &acc, int p, const Bias16 &c) {
-            if (p < 0) return;                              // padding lane of the last tile
+            if (G::NP != G::NTP && p < 0) return;           // padding lane of the last tile
 #pragma unroll
             for (int g = 0; g < 4; g++) {
                 half4 h, l;
@@ -505,7 +506,7 @@ __device__ inline void cnn16_forward(const NetWeights &nw_in, float *lds, InputF
     {
         const float *b3 = lbias + 96 + wave * 32;
         struct Head16 { f32x4 b[4]; half8 wh[2], wl[2]; };
-        float *hp = lds + G::HP_OFF + wave * 6 * G::NTP;
+        float *hp = lds + G::HP_OFF + wave * 8 * G::NTP;
         const char *whp = ldb + G::WH_OFF + ((wave * 4 + half) * 8 + (j < 8 ? j : 7)) * 32;
         conv3x3_f16<G, 64, 128, G::RS_A2, true, G::BPF, R3>(w3, ring3, ldb + G::A2H_OFF, ldb + G::A2L_OFF, wave, lane,
             [=]() {
@@ -538,17 +539,12 @@ __device__ inline void cnn16_forward(const NetWeights &nw_in, float *lds, InputF
                     hd = __builtin_amdgcn_mfma_f32_32x32x16_f16(c.wl[s2], xh8, hd, 0, 0, 0);
                     hd = __builtin_amdgcn_mfma_f32_32x32x16_f16(c.wh[s2], xl8, hd, 0, 0, 0);
                 }
-                // rows 0-3 of the head tile sit in registers 0-3 of lanes 0-31, rows 4-5 in
-                // registers 0-1 of lanes 32-63
-                float *dst = hp + tile * 32 + j;
-                if (p < 0) return;                          // padding lane of the last tile
-                if (!half) {
+                // rows 0-3 of the head tile sit in registers 0-3 of lanes 0-31, rows 4-7 in
+                // registers 0-3 of lanes 32-63 (rows 6, 7 are zero: their weights are)
+                if (G::NP != G::NTP && p < 0) return;       // padding lane of the last tile
+                float *dst = hp + (4 * half) * G::NTP + tile * 32 + j;
 #pragma unroll
-                    for (int c = 0; c < 4; c++) dst[c * G::NTP] = hd[c];
-                } else {
-                    dst[4 * G::NTP] = hd[0];
-                    dst[5 * G::NTP] = hd[1];
-                }
+                for (int c = 0; c < 4; c++) dst[c * G::NTP] = hd[c];
             }, &prof);
     }
     prof.mark(5);
