@@ -135,7 +135,7 @@ __device__ inline void cnn_tail(const NetWeights &nw, float *lds, Prof &prof)
         const int leaf = p / G::S, cell = p - leaf * G::S;
         lds[G::HF_OFF + leaf * G::HFS + c * G::S + cell] = s;
     }
-    if (G::VL > 2 * G::S && tid < G::T * (G::VL - 2 * G::S)) {       // zero the k padding of the value part
+    if constexpr (G::VL > 2 * G::S) if (tid < G::T * (G::VL - 2 * G::S)) {   // zero the k padding of the value part
         const int leaf = tid / (G::VL - 2 * G::S), e = tid - leaf * (G::VL - 2 * G::S);
         lds[G::HF_OFF + leaf * G::HFS + 6 * G::S + e] = 0.0f;
     }

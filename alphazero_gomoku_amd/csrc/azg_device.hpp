@@ -157,14 +157,24 @@ struct DevState {
     int *used;                     // [B] edges in use in the live arena
     unsigned char *cur;            // [B]
     long long *evals;              // [B] leaf evaluations that needed priors (profiling)
-    // per-game training samples of the game in progress
-    unsigned long long *s_bb;      // [B][S][2][MAXW] stones before the move
-    int *s_last;                   // [B][S] last_move before the move
-    int *s_ply;                    // [B][S] len(states) before the move
-    double *s_pi;                  // [B][S][S]
+    // per-game training samples, two banks per slot: the game in progress records into bank
+    // s_bank[g]; a slot restarted on the device (pipelined self-play) flips the bank, so the
+    // finished game's samples stay readable until they are drained
+    unsigned long long *s_bb;      // [B][2][S][2][MAXW] stones before the move
+    int *s_last;                   // [B][2][S] last_move before the move
+    int *s_ply;                    // [B][2][S] len(states) before the move
+    double *s_pi;                  // [B][2][S][S]
     int *s_count;                  // [B] samples recorded (= plies played by the engine)
+    unsigned char *s_bank;         // [B]
     long long *game_id;            // [B]
     unsigned char *drained;        // [B]
+    // record of the game that ended in the slot during the last advance (pipelined self-play)
+    long long *fin_id;             // [B] its game id
+    int *fin_count;                // [B] its number of samples
+    signed char *fin_flag;         // [B] 1: a game ended in this slot in the last advance
+    signed char *fin_winner;       // [B]
+    unsigned char *fin_bank;       // [B] bank holding its samples
+    unsigned long long *next_k;    // [1] games handed out so far (device-side restart counter)
     long long *stamps;             // [kStampWords] counters of a diagnostic build (-DAZG_STAMPS)
     NetWeights net;
 };

@@ -208,7 +208,13 @@ __device__ inline double np_sum(const double *a, int n)   // n <= 256
 }
 
 // ---------------------------------------------------------------- advance
-enum { ADV_SAMPLE = 1, ADV_RECORD = 2, ADV_BOARD = 4, ADV_REROOT = 8 };
+enum { ADV_SAMPLE = 1, ADV_RECORD = 2, ADV_BOARD = 4, ADV_REROOT = 8, ADV_RESTART = 16 };
+
+// index of sample t of the game recording into bank `bank` of slot g
+__device__ inline size_t sample_index(const DevState &st, int g, int bank, int t)
+{
+    return ((size_t)g * 2 + (size_t)bank) * (size_t)st.S + (size_t)t;
+}
 
 // Start a fresh root (TreeNode(None, 1.0), mcts_alphaZero.py:108,192) in arena `arena`.
 __device__ inline void fresh_root(const DevState &st, int g, int arena)
@@ -260,9 +266,13 @@ __device__ inline void wave_reroot(const DevState &st, int g, int c, int lane)
 // MCTSPlayer.get_action's tail (mcts_alphaZero.py:216-242) + Game.start_self_play's
 // bookkeeping (game.py:381-391) for one game per wave.  noise: [B][S] Dirichlet draws
 // in child order, u01: [B] uniforms (both from the game's numpy-legacy stream).
+// ADV_RESTART (pipelined self-play): a slot whose game ends is recorded in fin_* and restarted
+// at once as game first_id + k*stride, k drawn from the device counter (no restart once
+// k >= total, total < 0 = no limit), so the next search needs no host round trip.
 __global__ __launch_bounds__(256) void advance_kernel(DevState st, double temp, const double *noise,
                                                       const double *u01, const int *given, int flags,
-                                                      int *moves_out, double *pi_out)
+                                                      int *moves_out, double *pi_out, long long first_id,
+                                                      long long stride, long long total)
 {
     __shared__ double s_e[4][MAXS];
     __shared__ double s_c[4][MAXS];
@@ -273,6 +283,7 @@ __global__ __launch_bounds__(256) void advance_kernel(DevState st, double temp, 
     int move = -1;
     const bool live = st.status[g] == 0;
     const bool want = live && ((flags & ADV_SAMPLE) || (given && given[g] >= 0));
+    if ((flags & ADV_RESTART) && lane == 0) st.fin_flag[g] = 0;
     if (!want) {
         if (moves_out && lane == 0) moves_out[g] = -1;
         return;
@@ -337,12 +348,13 @@ __global__ __launch_bounds__(256) void advance_kernel(DevState st, double temp, 
     if (flags & ADV_RECORD) {
         const int sc = st.s_count[g];
         if (sc < S) {
-            double *pi = st.s_pi + ((size_t)g * S + sc) * S;
+            const size_t si = sample_index(st, g, st.s_bank[g], sc);
+            double *pi = st.s_pi + si * S;
             for (int i = lane; i < S; i += WAVE) pi[i] = 0.0;
             wg_fence();
             for (int i = lane; i < K; i += WAVE) pi[meta_act(t.meta[base + i])] = e[i];
-            if (lane < 2 * MAXW) st.s_bb[((size_t)g * S + sc) * 2 * MAXW + lane] = st.bb[(size_t)g * 2 * MAXW + lane];
-            if (lane == 0) { st.s_last[(size_t)g * S + sc] = st.last_move[g]; st.s_ply[(size_t)g * S + sc] = ply; st.s_count[g] = sc + 1; }
+            if (lane < 2 * MAXW) st.s_bb[si * 2 * MAXW + lane] = st.bb[(size_t)g * 2 * MAXW + lane];
+            if (lane == 0) { st.s_last[si] = st.last_move[g]; st.s_ply[si] = ply; st.s_count[g] = sc + 1; }
         }
     }
     if (pi_out) {
@@ -381,6 +393,29 @@ __global__ __launch_bounds__(256) void advance_kernel(DevState st, double temp, 
             wave_reroot(st, g, base + child_idx, lane);
         }
     }
+    if ((flags & ADV_RESTART) && ended) {
+        // Game.start_self_play returned (game.py:393-416); the next call's init_board /
+        // reset_player (game.py:363, mcts_alphaZero.py:208-209) happen here for the slot
+        long long k = 0;
+        if (lane == 0) {
+            st.fin_flag[g] = 1;
+            st.fin_id[g] = st.game_id[g];
+            st.fin_count[g] = st.s_count[g];
+            st.fin_winner[g] = st.winner[g];
+            st.fin_bank[g] = st.s_bank[g];
+            k = (long long)atomicAdd(st.next_k, 1ULL);
+        }
+        k = __shfl(k, 0);
+        if (total < 0 || k < total) {
+            if (lane < 2 * MAXW) st.bb[(size_t)g * 2 * MAXW + lane] = 0;
+            if (lane == 0) {
+                st.ply[g] = 0; st.last_move[g] = -1; st.first_player[g] = 1;
+                st.status[g] = 0; st.winner[g] = -1;
+                st.s_count[g] = 0; st.s_bank[g] ^= 1;
+                st.game_id[g] = first_id + k * stride;
+            }
+        }
+    }
 }
 
 // MCTS.update_with_move alone (board untouched): moves[g] >= 0 re-root, -1 fresh, -2 skip.
@@ -414,7 +449,7 @@ __global__ void reset_kernel(DevState st, const unsigned char *mask, const long 
     for (int i = 0; i < 2 * MAXW; i++) st.bb[(size_t)g * 2 * MAXW + i] = 0;
     st.ply[g] = 0; st.last_move[g] = -1; st.first_player[g] = 1;
     st.status[g] = 0; st.winner[g] = -1; st.err[g] = 0;
-    st.s_count[g] = 0; st.drained[g] = 0;
+    st.s_count[g] = 0; st.drained[g] = 0; st.fin_flag[g] = 0;
     st.game_id[g] = ids ? ids[g] : (long long)g;
     fresh_root(st, g, 0);
 }
@@ -459,16 +494,21 @@ __global__ void states_kernel(DevState st, float *out)
 }
 
 // (state, pi, z) tuples of finished games (game.py:393-416).  map_g/map_t give slot and
-// sample index of output row i.
-__global__ void drain_kernel(DevState st, int n, const int *map_g, const int *map_t, float *states,
-                             double *pi, float *z, long long *gid, int *ply_out)
+// sample index of output row i.  Without map_aux the game is the one still sitting in the slot;
+// with it (pipelined self-play: the slot may already hold the next game) map_aux[i] =
+// bank | (winner + 1) << 8 and map_id[i] identify the finished game.
+__global__ void drain_kernel(DevState st, int n, const int *map_g, const int *map_t, const int *map_aux,
+                             const long long *map_id, float *states, double *pi, float *z, long long *gid,
+                             int *ply_out)
 {
     const int i = blockIdx.x;
     if (i >= n) return;
     const int g = map_g[i], t = map_t[i];
     const int S = st.S, N = st.N;
-    const u64(*bb)[MAXW] = reinterpret_cast<const u64(*)[MAXW]>(st.s_bb + ((size_t)g * S + t) * 2 * MAXW);
-    const int ply = st.s_ply[(size_t)g * S + t], last = st.s_last[(size_t)g * S + t];
+    const int bank = map_aux ? (map_aux[i] & 1) : st.s_bank[g];
+    const size_t si = sample_index(st, g, bank, t);
+    const u64(*bb)[MAXW] = reinterpret_cast<const u64(*)[MAXW]>(st.s_bb + si * 2 * MAXW);
+    const int ply = st.s_ply[si], last = st.s_last[si];
     const int cur = player_at(st.first_player[g], ply);
     if (states)
         for (int idx = threadIdx.x; idx < 4 * S; idx += blockDim.x) {
@@ -477,11 +517,11 @@ __global__ void drain_kernel(DevState st, int n, const int *map_g, const int *ma
         }
     if (pi)
         for (int idx = threadIdx.x; idx < S; idx += blockDim.x)
-            pi[(size_t)i * S + idx] = st.s_pi[((size_t)g * S + t) * S + idx];
+            pi[(size_t)i * S + idx] = st.s_pi[si * S + idx];
     if (threadIdx.x == 0) {
-        const int w = st.winner[g];
+        const int w = map_aux ? (map_aux[i] >> 8) - 1 : (int)st.winner[g];
         if (z) z[i] = (w == -1) ? 0.0f : (w == cur ? 1.0f : -1.0f);
-        if (gid) gid[i] = st.game_id[g];
+        if (gid) gid[i] = map_id ? map_id[i] : st.game_id[g];
         if (ply_out) ply_out[i] = ply;
     }
 }

@@ -28,21 +28,39 @@ struct azg_handle {
     bool have_weights = false;
     float *d_weights = nullptr;
     // host mirrors, refreshed after every state-changing call
-    std::vector<int> h_ply, h_scount, h_err;
-    std::vector<signed char> h_status, h_winner;
-    std::vector<unsigned char> h_drained;
+    std::vector<int> h_ply, h_scount, h_err, h_fin_count;
+    std::vector<signed char> h_status, h_winner, h_fin_flag, h_fin_winner;
+    std::vector<unsigned char> h_drained, h_fin_bank;
+    std::vector<long long> h_game_id, h_fin_id;
     std::vector<NpLegacyRng> rng;
     // pinned staging
     double *h_noise = nullptr, *h_u = nullptr;
     int *h_moves = nullptr;
-    int *h_ints = nullptr;           // pinned copy of the mirror block: ply | s_count | err | status | winner
-    int *d_mirror = nullptr;         // device block the five arrays above live in (one copy per refresh)
+    // mirror block (one D2H copy per refresh): i64 game_id | fin_id, i32 ply | s_count | err |
+    // fin_count, i8 status | winner | fin_flag | fin_winner | fin_bank  = 37 bytes per slot
+    char *h_mirror = nullptr;        // pinned
+    char *d_mirror = nullptr;
     bool mirrors_fresh = false;
+    size_t mirror_events = 0;        // profiling events recorded before the last mirror copy
+    // pipelined self-play (azg_selfplay_*)
+    struct Pipeline {
+        bool active = false;
+        double temp = 1.0;
+        uint32_t seed0 = 0;
+        long long first = 0, stride = 1, total = -1;
+        hipEvent_t ev_mirror = nullptr;
+        hipStream_t copy_stream = nullptr;
+        int par = 0;                             // parity of the sample set being produced
+        int pend_n = 0, pend_games = 0;          // enqueued in the last step, complete by the next one
+        int ready_n = 0, ready_games = 0, ready_par = 0;
+        int *h_map = nullptr;                    // pinned: per parity [3][B*S] slot | sample | aux
+        long long *h_ids = nullptr;              // pinned: per parity [B*S]
+    } sp;
     double *d_noise = nullptr, *d_u = nullptr, *d_pi = nullptr;
     int *d_moves = nullptr, *d_given = nullptr;
     // grow-on-demand device scratch
-    void *scratch[8] = {nullptr};
-    size_t scratch_sz[8] = {0};
+    void *scratch[32] = {nullptr};
+    size_t scratch_sz[32] = {0};
     // profiling
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
     size_t ev_pending = 0;
@@ -146,39 +164,66 @@ static bool pick_eval(int N, int cnn_mode, EvalLaunch *out)
 }
 
 // ---------------------------------------------------------------- mirrors / profiling
-static int harvest_events(azg_handle *h)
+static int harvest_events(azg_handle *h, size_t count)
 {
-    for (size_t i = 0; i < h->ev_pending; i++) {
+    count = std::min(count, h->ev_pending);
+    for (size_t i = 0; i < count; i++) {
         float ms = 0.f;
         HIPCHK(h, hipEventElapsedTime(&ms, h->ev_pool[i].first, h->ev_pool[i].second));
         h->prof_ms += ms;
         h->prof_launches++;
     }
-    h->ev_pending = 0;
+    // events of launches still in flight (pipelined self-play) move to the front
+    std::rotate(h->ev_pool.begin(), h->ev_pool.begin() + count, h->ev_pool.begin() + h->ev_pending);
+    h->ev_pending -= count;
     return AZG_OK;
 }
 
-static int refresh_mirrors(azg_handle *h)
+static size_t mirror_bytes(int B) { return (size_t)B * 37; }
+
+static int mirrors_enqueue(azg_handle *h)
+{
+    HIPCHK(h, hipMemcpyAsync(h->h_mirror, h->d_mirror, mirror_bytes(h->cfg.n_games), hipMemcpyDeviceToHost, h->stream));
+    h->mirror_events = h->ev_pending;
+    return AZG_OK;
+}
+
+// after the copy of mirrors_enqueue has completed
+static int mirrors_unpack(azg_handle *h)
 {
     const int B = h->cfg.n_games;
-    HIPCHK(h, hipMemcpyAsync(h->h_ints, h->d_mirror, (size_t)B * 14, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    const long long *l = reinterpret_cast<const long long *>(h->h_mirror);
+    const int *i32 = reinterpret_cast<const int *>(h->h_mirror + (size_t)B * 16);
+    const signed char *i8 = reinterpret_cast<const signed char *>(h->h_mirror + (size_t)B * 32);
     for (int g = 0; g < B; g++) {
-        const signed char *sc = reinterpret_cast<const signed char *>(h->h_ints + 3 * B);
-        h->h_status[g] = sc[g];
-        h->h_winner[g] = sc[B + g];
-        h->h_ply[g] = h->h_ints[g];
-        h->h_scount[g] = h->h_ints[B + g];
-        h->h_err[g] = h->h_ints[2 * B + g];
+        h->h_game_id[g] = l[g];
+        h->h_fin_id[g] = l[B + g];
+        h->h_ply[g] = i32[g];
+        h->h_scount[g] = i32[B + g];
+        h->h_err[g] = i32[2 * B + g];
+        h->h_fin_count[g] = i32[3 * B + g];
+        h->h_status[g] = i8[g];
+        h->h_winner[g] = i8[B + g];
+        h->h_fin_flag[g] = i8[2 * B + g];
+        h->h_fin_winner[g] = i8[3 * B + g];
+        h->h_fin_bank[g] = (unsigned char)i8[4 * B + g];
     }
     h->mirrors_fresh = true;
-    int rc = harvest_events(h);
+    int rc = harvest_events(h, h->mirror_events);
     if (rc) return rc;
     for (int g = 0; g < B; g++) {
         if (h->h_err[g] & 1) return fail(h, AZG_EARENA, "slot %d: search tree outgrew its arena (arena_nodes=%d)", g, h->cfg.arena_nodes);
         if (h->h_err[g] & 2) return fail(h, AZG_EMOVE, "slot %d: illegal move", g);
     }
     return AZG_OK;
+}
+
+static int refresh_mirrors(azg_handle *h)
+{
+    int rc = mirrors_enqueue(h);
+    if (rc) return rc;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return mirrors_unpack(h);
 }
 
 // ---------------------------------------------------------------- create / destroy
@@ -195,7 +240,11 @@ extern "C" void azg_destroy(azg_handle *h)
     if (h->h_noise) (void)hipHostFree(h->h_noise);
     if (h->h_u) (void)hipHostFree(h->h_u);
     if (h->h_moves) (void)hipHostFree(h->h_moves);
-    if (h->h_ints) (void)hipHostFree(h->h_ints);
+    if (h->h_mirror) (void)hipHostFree(h->h_mirror);
+    if (h->sp.h_map) (void)hipHostFree(h->sp.h_map);
+    if (h->sp.h_ids) (void)hipHostFree(h->sp.h_ids);
+    if (h->sp.ev_mirror) (void)hipEventDestroy(h->sp.ev_mirror);
+    if (h->sp.copy_stream) (void)hipStreamDestroy(h->sp.copy_stream);
     for (auto &e : h->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -214,12 +263,20 @@ static int create_impl(azg_handle *h)
     const size_t E = (size_t)B * 2 * st.cap;
     int rc;
     if ((rc = dev_alloc(h, &st.bb, (size_t)B * 2 * MAXW))) return rc;
-    if ((rc = dev_alloc(h, &h->d_mirror, ((size_t)B * 14 + 3) / 4 + 4))) return rc;
-    st.ply = h->d_mirror;
-    st.s_count = h->d_mirror + B;
-    st.err = h->d_mirror + 2 * B;
-    st.status = reinterpret_cast<signed char *>(h->d_mirror + 3 * B);
+    if ((rc = dev_alloc(h, &h->d_mirror, mirror_bytes(B) + 16))) return rc;
+    st.game_id = reinterpret_cast<long long *>(h->d_mirror);
+    st.fin_id = st.game_id + B;
+    st.ply = reinterpret_cast<int *>(h->d_mirror + (size_t)B * 16);
+    st.s_count = st.ply + B;
+    st.err = st.ply + 2 * B;
+    st.fin_count = st.ply + 3 * B;
+    st.status = reinterpret_cast<signed char *>(h->d_mirror + (size_t)B * 32);
     st.winner = st.status + B;
+    st.fin_flag = st.status + 2 * B;
+    st.fin_winner = st.status + 3 * B;
+    st.fin_bank = reinterpret_cast<unsigned char *>(st.status + 4 * B);
+    if ((rc = dev_alloc(h, &st.s_bank, B))) return rc;
+    if ((rc = dev_alloc(h, &st.next_k, 1))) return rc;
     if ((rc = dev_alloc(h, &st.last_move, B))) return rc;
     if ((rc = dev_alloc(h, &st.first_player, B))) return rc;
     if ((rc = dev_alloc(h, &st.eP, E, false))) return rc;
@@ -230,11 +287,10 @@ static int create_impl(azg_handle *h)
     if ((rc = dev_alloc(h, &st.used, B))) return rc;
     if ((rc = dev_alloc(h, &st.cur, B))) return rc;
     if ((rc = dev_alloc(h, &st.evals, B))) return rc;
-    if ((rc = dev_alloc(h, &st.s_bb, (size_t)B * S * 2 * MAXW, false))) return rc;
-    if ((rc = dev_alloc(h, &st.s_last, (size_t)B * S, false))) return rc;
-    if ((rc = dev_alloc(h, &st.s_ply, (size_t)B * S, false))) return rc;
-    if ((rc = dev_alloc(h, &st.s_pi, (size_t)B * S * S, false))) return rc;
-    if ((rc = dev_alloc(h, &st.game_id, B))) return rc;
+    if ((rc = dev_alloc(h, &st.s_bb, (size_t)B * 2 * S * 2 * MAXW, false))) return rc;
+    if ((rc = dev_alloc(h, &st.s_last, (size_t)B * 2 * S, false))) return rc;
+    if ((rc = dev_alloc(h, &st.s_ply, (size_t)B * 2 * S, false))) return rc;
+    if ((rc = dev_alloc(h, &st.s_pi, (size_t)B * 2 * S * S, false))) return rc;
     if ((rc = dev_alloc(h, &st.drained, B))) return rc;
     if ((rc = dev_alloc(h, &st.stamps, kStampWords))) return rc;
     if ((rc = dev_alloc(h, &h->d_noise, (size_t)B * S))) return rc;
@@ -245,9 +301,11 @@ static int create_impl(azg_handle *h)
     HIPCHK(h, hipHostMalloc((void **)&h->h_noise, (size_t)B * S * sizeof(double)));
     HIPCHK(h, hipHostMalloc((void **)&h->h_u, (size_t)B * sizeof(double)));
     HIPCHK(h, hipHostMalloc((void **)&h->h_moves, (size_t)B * sizeof(int)));
-    HIPCHK(h, hipHostMalloc((void **)&h->h_ints, (size_t)B * 14 + 16));
-    h->h_ply.assign(B, 0); h->h_scount.assign(B, 0); h->h_err.assign(B, 0);
+    HIPCHK(h, hipHostMalloc((void **)&h->h_mirror, mirror_bytes(B) + 16));
+    h->h_ply.assign(B, 0); h->h_scount.assign(B, 0); h->h_err.assign(B, 0); h->h_fin_count.assign(B, 0);
     h->h_status.assign(B, 2); h->h_winner.assign(B, -1); h->h_drained.assign(B, 1);
+    h->h_fin_flag.assign(B, 0); h->h_fin_winner.assign(B, -1); h->h_fin_bank.assign(B, 0);
+    h->h_game_id.assign(B, 0); h->h_fin_id.assign(B, 0);
     h->rng.resize(B);
     // every slot starts idle (status 2) until azg_reset_games
     HIPCHK(h, hipMemsetAsync(st.status, 2, B, h->stream));
@@ -469,9 +527,13 @@ extern "C" int azg_set_weights(azg_handle *h, const float *const ptrs[16], int l
 }
 
 // ---------------------------------------------------------------- game control
+#define NOT_WHILE_PIPELINED(h) \
+    do { if ((h)->sp.active) return fail(h, AZG_ESTATE, "not valid between azg_selfplay_begin and azg_selfplay_end"); } while (0)
+
 extern "C" int azg_reset_games(azg_handle *h, const uint8_t *mask, const uint32_t *seeds, const int64_t *game_ids)
 {
     if (!h) return AZG_EINVAL;
+    NOT_WHILE_PIPELINED(h);
     HIPCHK(h, hipSetDevice(h->cfg.device));
     const int B = h->cfg.n_games;
     void *d_mask = nullptr, *d_ids = nullptr;
@@ -499,6 +561,7 @@ extern "C" int azg_set_position(azg_handle *h, int slot, const uint64_t stones1[
                                 int last_move, int current_player)
 {
     if (!h || !stones1 || !stones2) return fail(h, AZG_EINVAL, "null argument");
+    NOT_WHILE_PIPELINED(h);
     if (slot < 0 || slot >= h->cfg.n_games) return fail(h, AZG_EINVAL, "slot %d out of range", slot);
     if (current_player != 1 && current_player != 2) return fail(h, AZG_EINVAL, "current_player must be 1 or 2");
     HIPCHK(h, hipSetDevice(h->cfg.device));
@@ -564,7 +627,7 @@ extern "C" int azg_root_stats(azg_handle *h, int32_t *visits, double *q, double 
     if (prior) HIPCHK(h, hipMemcpyAsync(prior, dp, (size_t)B * S * sizeof(double), hipMemcpyDefault, h->stream));
     if (root_visits) HIPCHK(h, hipMemcpyAsync(root_visits, dr, (size_t)B * sizeof(int), hipMemcpyDefault, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    return harvest_events(h);
+    return harvest_events(h, h->ev_pending);
 }
 
 static void make_noise(azg_handle *h)
@@ -591,6 +654,7 @@ static void make_noise(azg_handle *h)
 
 static int advance_common(azg_handle *h, double temp, const int32_t *given, int flags, int32_t *moves_out, double *pi_out)
 {
+    NOT_WHILE_PIPELINED(h);
     HIPCHK(h, hipSetDevice(h->cfg.device));
     const int B = h->cfg.n_games, S = h->st.S;
     if (!(temp > 0.0)) return fail(h, AZG_EINVAL, "temp must be positive");
@@ -604,7 +668,7 @@ static int advance_common(azg_handle *h, double temp, const int32_t *given, int 
     }
     hipLaunchKernelGGL(advance_kernel, dim3((B + 3) / 4), dim3(256), 0, h->stream, h->st, temp, h->d_noise,
                        h->d_u, (flags & ADV_SAMPLE) ? (const int *)nullptr : h->d_given, flags, h->d_moves,
-                       pi_out ? h->d_pi : (double *)nullptr);
+                       pi_out ? h->d_pi : (double *)nullptr, 0LL, 1LL, 0LL);
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipMemcpyAsync(h->h_moves, h->d_moves, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, h->stream));
     if (pi_out) HIPCHK(h, hipMemcpyAsync(pi_out, h->d_pi, (size_t)B * S * sizeof(double), hipMemcpyDefault, h->stream));
@@ -628,6 +692,7 @@ extern "C" int azg_advance(azg_handle *h, const int32_t *moves, int record, doub
 extern "C" int azg_update_with_move(azg_handle *h, const int32_t *moves)
 {
     if (!h || !moves) return fail(h, AZG_EINVAL, "null argument");
+    NOT_WHILE_PIPELINED(h);
     HIPCHK(h, hipSetDevice(h->cfg.device));
     const int B = h->cfg.n_games;
     for (int g = 0; g < B; g++) h->h_moves[g] = moves[g];
@@ -672,6 +737,7 @@ extern "C" int azg_drain_samples(azg_handle *h, int max_samples, float *states, 
                                  int64_t *game_id, int32_t *ply, int *n_out)
 {
     if (!h || !n_out) return fail(h, AZG_EINVAL, "null argument");
+    NOT_WHILE_PIPELINED(h);
     HIPCHK(h, hipSetDevice(h->cfg.device));
     const int B = h->cfg.n_games, S = h->st.S;
     std::vector<int> map_g, map_t;
@@ -699,7 +765,7 @@ extern "C" int azg_drain_samples(azg_handle *h, int max_samples, float *states, 
     HIPCHK(h, hipMemcpyAsync(dg, map_g.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemcpyAsync(dt, map_t.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, h->stream));
     hipLaunchKernelGGL(drain_kernel, dim3(n), dim3(64), 0, h->stream, h->st, n, (const int *)dg, (const int *)dt,
-                       states ? (float *)ds : nullptr, pi ? (double *)dp : nullptr, (float *)dz, (long long *)di, (int *)dl);
+                       (const int *)nullptr, (const long long *)nullptr, states ? (float *)ds : nullptr, pi ? (double *)dp : nullptr, (float *)dz, (long long *)di, (int *)dl);
     HIPCHK(h, hipGetLastError());
     if (states) HIPCHK(h, hipMemcpyAsync(states, ds, (size_t)n * 4 * S * sizeof(float), hipMemcpyDefault, h->stream));
     if (pi) HIPCHK(h, hipMemcpyAsync(pi, dp, (size_t)n * S * sizeof(double), hipMemcpyDefault, h->stream));
@@ -776,6 +842,170 @@ extern "C" int azg_board_step_batch(azg_handle *h, int n, uint64_t *stones, int3
     return AZG_OK;
 }
 
+
+// ---------------------------------------------------------------- pipelined self-play
+// The loop train.py:146 runs (collect_selfplay_data -> Game.start_self_play, game.py:360-416)
+// with every slot kept busy and no host round trip between a move step and the next search:
+//   search(k) | noise upload, advance(k) + on-device restart of finished slots, mirror copy |
+//   search(k+1) | drain of the games that finished in step k | ...
+// The host waits only for the mirror copy; it prepares the exploration noise of step k+1 and
+// fetches the drained samples while search(k+1) runs.
+static void sp_seed_slot(azg_handle *h, int g)
+{
+    h->rng[g].seed((uint32_t)((long long)h->sp.seed0 + h->h_game_id[g]));
+}
+
+extern "C" int azg_selfplay_begin(azg_handle *h, double temp, uint32_t seed0, int64_t first_id, int64_t stride,
+                                  int64_t total)
+{
+    if (!h) return AZG_EINVAL;
+    if (h->sp.active) return fail(h, AZG_ESTATE, "self-play pipeline already running");
+    if (!(temp > 0.0)) return fail(h, AZG_EINVAL, "temp must be positive");
+    if (stride < 1) return fail(h, AZG_EINVAL, "stride must be positive");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    const int B = h->cfg.n_games, S = h->st.S;
+    auto &sp = h->sp;
+    if (!sp.ev_mirror) HIPCHK(h, hipEventCreateWithFlags(&sp.ev_mirror, hipEventDisableTiming));
+    if (!sp.copy_stream) HIPCHK(h, hipStreamCreateWithFlags(&sp.copy_stream, hipStreamNonBlocking));
+    if (!sp.h_map) HIPCHK(h, hipHostMalloc((void **)&sp.h_map, (size_t)2 * 3 * B * S * sizeof(int)));
+    if (!sp.h_ids) HIPCHK(h, hipHostMalloc((void **)&sp.h_ids, (size_t)2 * B * S * sizeof(long long)));
+    sp.temp = temp; sp.seed0 = seed0; sp.first = first_id; sp.stride = stride; sp.total = total;
+    sp.par = 0; sp.pend_n = sp.pend_games = sp.ready_n = sp.ready_games = 0;
+    // slots 0..B-1 start games k = 0..B-1 of this engine's sequence
+    std::vector<uint8_t> mask(B, 0);
+    std::vector<uint32_t> seeds(B, 0);
+    std::vector<int64_t> ids(B, 0);
+    int started = 0;
+    for (int g = 0; g < B; g++) {
+        if (total >= 0 && g >= total) continue;
+        mask[g] = 1;
+        ids[g] = first_id + (int64_t)g * stride;
+        seeds[g] = (uint32_t)((long long)seed0 + ids[g]);
+        started++;
+    }
+    int rc = azg_reset_games(h, mask.data(), seeds.data(), ids.data());
+    if (rc) return rc;
+    // slots that get no game must not keep an older one alive
+    if (started < B) {
+        HIPCHK(h, hipMemsetAsync(h->st.status + started, 2, B - started, h->stream));
+        if ((rc = refresh_mirrors(h))) return rc;
+    }
+    const unsigned long long next = (unsigned long long)B;
+    HIPCHK(h, hipMemcpyAsync(h->st.next_k, &next, sizeof(next), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if ((rc = azg_search(h))) return rc;
+    sp.active = true;
+    return AZG_OK;
+}
+
+// the drain of the games that ended in the step just taken, behind the search already enqueued
+static int sp_enqueue_drain(azg_handle *h)
+{
+    auto &sp = h->sp;
+    const int B = h->cfg.n_games, S = h->st.S;
+    const size_t cap = (size_t)B * S;
+    int *mg = sp.h_map + (size_t)sp.par * 3 * cap, *mt = mg + cap, *ma = mt + cap;
+    long long *mi = sp.h_ids + (size_t)sp.par * cap;
+    int n = 0, games = 0;
+    for (int g = 0; g < B; g++) {
+        if (!h->h_fin_flag[g]) continue;
+        games++;
+        const int aux = (h->h_fin_bank[g] & 1) | ((h->h_fin_winner[g] + 1) << 8);
+        for (int t = 0; t < h->h_fin_count[g]; t++, n++) { mg[n] = g; mt[n] = t; ma[n] = aux; mi[n] = h->h_fin_id[g]; }
+    }
+    sp.pend_n = n; sp.pend_games = games;
+    if (n == 0) return AZG_OK;
+    const int base = 8 + sp.par * 9;
+    void *dg, *dt, *da, *di, *ds, *dp, *dz, *dgid, *dply;
+    int rc;
+    if ((rc = scratch_get(h, base + 0, (size_t)n * sizeof(int), &dg))) return rc;
+    if ((rc = scratch_get(h, base + 1, (size_t)n * sizeof(int), &dt))) return rc;
+    if ((rc = scratch_get(h, base + 2, (size_t)n * sizeof(int), &da))) return rc;
+    if ((rc = scratch_get(h, base + 3, (size_t)n * sizeof(long long), &di))) return rc;
+    if ((rc = scratch_get(h, base + 4, (size_t)n * 4 * S * sizeof(float), &ds))) return rc;
+    if ((rc = scratch_get(h, base + 5, (size_t)n * S * sizeof(double), &dp))) return rc;
+    if ((rc = scratch_get(h, base + 6, (size_t)n * sizeof(float), &dz))) return rc;
+    if ((rc = scratch_get(h, base + 7, (size_t)n * sizeof(long long), &dgid))) return rc;
+    if ((rc = scratch_get(h, base + 8, (size_t)n * sizeof(int), &dply))) return rc;
+    HIPCHK(h, hipMemcpyAsync(dg, mg, (size_t)n * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(dt, mt, (size_t)n * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(da, ma, (size_t)n * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(di, mi, (size_t)n * sizeof(long long), hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(drain_kernel, dim3(n), dim3(64), 0, h->stream, h->st, n, (const int *)dg, (const int *)dt,
+                       (const int *)da, (const long long *)di, (float *)ds, (double *)dp, (float *)dz,
+                       (long long *)dgid, (int *)dply);
+    HIPCHK(h, hipGetLastError());
+    return AZG_OK;
+}
+
+extern "C" int azg_selfplay_step(azg_handle *h, int *games_finished, int *samples_ready)
+{
+    if (!h) return AZG_EINVAL;
+    if (!h->sp.active) return fail(h, AZG_ESTATE, "azg_selfplay_begin has not been called");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    auto &sp = h->sp;
+    const int B = h->cfg.n_games, S = h->st.S;
+    make_noise(h);                                  // while the search enqueued last time runs
+    HIPCHK(h, hipMemcpyAsync(h->d_noise, h->h_noise, (size_t)B * S * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->d_u, h->h_u, (size_t)B * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(advance_kernel, dim3((B + 3) / 4), dim3(256), 0, h->stream, h->st, sp.temp, h->d_noise, h->d_u,
+                       (const int *)nullptr, ADV_SAMPLE | ADV_RECORD | ADV_BOARD | ADV_REROOT | ADV_RESTART,
+                       (int *)nullptr, (double *)nullptr, (long long)sp.first, (long long)sp.stride, (long long)sp.total);
+    HIPCHK(h, hipGetLastError());
+    int rc = mirrors_enqueue(h);
+    if (rc) return rc;
+    HIPCHK(h, hipEventRecord(sp.ev_mirror, h->stream));
+    if ((rc = azg_search(h))) return rc;            // the next search starts without waiting for the host
+    HIPCHK(h, hipEventSynchronize(sp.ev_mirror));
+    if ((rc = mirrors_unpack(h))) return rc;
+    h->mirrors_fresh = false;                       // a search is in flight
+    // what the previous step enqueued behind its search is complete now
+    sp.ready_n = sp.pend_n; sp.ready_games = sp.pend_games; sp.ready_par = sp.par ^ 1;
+    int fin = 0;
+    for (int g = 0; g < B; g++) {
+        if (!h->h_fin_flag[g]) continue;
+        fin++;
+        if (h->h_status[g] == 0) sp_seed_slot(h, g);   // restarted with a new game id
+    }
+    if ((rc = sp_enqueue_drain(h))) return rc;
+    sp.par ^= 1;
+    if (games_finished) *games_finished = fin;
+    if (samples_ready) *samples_ready = sp.ready_n;
+    return AZG_OK;
+}
+
+extern "C" int azg_selfplay_fetch(azg_handle *h, float *states, double *pi, float *z, int64_t *game_id, int32_t *ply)
+{
+    if (!h) return AZG_EINVAL;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    auto &sp = h->sp;
+    const int n = sp.ready_n, S = h->st.S;
+    if (n == 0) return AZG_OK;
+    const int base = 8 + sp.ready_par * 9;
+    hipStream_t cs = sp.copy_stream;
+    if (states) HIPCHK(h, hipMemcpyAsync(states, h->scratch[base + 4], (size_t)n * 4 * S * sizeof(float), hipMemcpyDefault, cs));
+    if (pi) HIPCHK(h, hipMemcpyAsync(pi, h->scratch[base + 5], (size_t)n * S * sizeof(double), hipMemcpyDefault, cs));
+    if (z) HIPCHK(h, hipMemcpyAsync(z, h->scratch[base + 6], (size_t)n * sizeof(float), hipMemcpyDefault, cs));
+    if (game_id) HIPCHK(h, hipMemcpyAsync(game_id, h->scratch[base + 7], (size_t)n * sizeof(long long), hipMemcpyDefault, cs));
+    if (ply) HIPCHK(h, hipMemcpyAsync(ply, h->scratch[base + 8], (size_t)n * sizeof(int), hipMemcpyDefault, cs));
+    HIPCHK(h, hipStreamSynchronize(cs));
+    return AZG_OK;
+}
+
+extern "C" int azg_selfplay_end(azg_handle *h, int *samples_ready)
+{
+    if (!h) return AZG_EINVAL;
+    if (!h->sp.active) return fail(h, AZG_ESTATE, "azg_selfplay_begin has not been called");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    auto &sp = h->sp;
+    sp.active = false;
+    int rc = refresh_mirrors(h);                    // waits for the search in flight and the last drain
+    sp.ready_n = sp.pend_n; sp.ready_games = sp.pend_games; sp.ready_par = sp.par ^ 1;
+    sp.pend_n = sp.pend_games = 0;
+    if (samples_ready) *samples_ready = sp.ready_n;
+    return rc;
+}
+
 // Diagnostic builds (-DAZG_STAMPS) only: 32 summed phase counters, then per workgroup of the
 // last search launch (loop time in 100 MHz ticks, hardware id) for the first 2048 workgroups.
 extern "C" int azg_debug_stamps(azg_handle *h, long long out[kStampWords])
@@ -793,7 +1023,7 @@ extern "C" int azg_profile(azg_handle *h, int64_t *launches, double *ms, int64_t
     if (!h) return AZG_EINVAL;
     HIPCHK(h, hipSetDevice(h->cfg.device));
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    int rc = harvest_events(h);
+    int rc = harvest_events(h, h->ev_pending);
     if (rc) return rc;
     const int B = h->cfg.n_games;
     std::vector<long long> ev(B);

@@ -157,6 +157,42 @@ class SelfPlayEngine:
                                            C.byref(n)))
         return n.value
 
+    # ---- pipelined self-play (azg_selfplay_*) --------------------------------------
+    def selfplay_begin(self, temp=1.0, seed0=0, first_game_id=0, game_id_stride=1, total=None):
+        self._chk(self.L.azg_selfplay_begin(self.h, float(temp), int(seed0) & 0xFFFFFFFF, int(first_game_id),
+                                            int(game_id_stride), -1 if total is None else int(total)))
+
+    def selfplay_step(self):
+        """One move for every live slot -> (games finished in this step, samples ready to fetch)."""
+        fin, ready = C.c_int(0), C.c_int(0)
+        self._chk(self.L.azg_selfplay_step(self.h, C.byref(fin), C.byref(ready)))
+        return fin.value, ready.value
+
+    def selfplay_end(self):
+        ready = C.c_int(0)
+        self._chk(self.L.azg_selfplay_end(self.h, C.byref(ready)))
+        return ready.value
+
+    def selfplay_fetch(self, n, device=False):
+        """The n ready samples as a dict of numpy arrays (or torch CUDA tensors with device=True)."""
+        if device:
+            import torch
+            dev = torch.device("cuda", self.device)
+            t = dict(states=torch.empty((n, 4, self.N, self.N), dtype=torch.float32, device=dev),
+                     pi=torch.empty((n, self.S), dtype=torch.float64, device=dev),
+                     z=torch.empty(n, dtype=torch.float32, device=dev),
+                     game_id=torch.empty(n, dtype=torch.int64, device=dev),
+                     ply=torch.empty(n, dtype=torch.int32, device=dev))
+            if n:
+                self._chk(self.L.azg_selfplay_fetch(self.h, *[C.c_void_p(t[k].data_ptr())
+                                                             for k in ("states", "pi", "z", "game_id", "ply")]))
+            return t
+        t = dict(states=np.zeros((n, 4, self.N, self.N), dtype=np.float32), pi=np.zeros((n, self.S)),
+                 z=np.zeros(n, dtype=np.float32), game_id=np.zeros(n, dtype=np.int64), ply=np.zeros(n, dtype=np.int32))
+        if n:
+            self._chk(self.L.azg_selfplay_fetch(self.h, *[_ptr(t[k]) for k in ("states", "pi", "z", "game_id", "ply")]))
+        return t
+
     def eval_batch(self, states):
         st = np.ascontiguousarray(states, dtype=np.float32).reshape(-1, 4, self.N, self.N)
         n = st.shape[0]
@@ -194,7 +230,7 @@ class SelfPlayEngine:
 
     # ---- batched self-play -----------------------------------------------------
     def play_games(self, n_games_total, temp=1.0, seed0=0, first_game_id=0, game_id_stride=1,
-                   on_samples=None, max_moves=None):
+                   on_samples=None, max_moves=None, pipelined=True):
         """Play `n_games_total` self-play games through the B slots, refilling a slot as
         soon as its game ends (game k has id = first_game_id + k * game_id_stride and draws
         its noise from numpy's legacy RandomState seeded with seed0 + id).  Returns
@@ -202,10 +238,12 @@ class SelfPlayEngine:
         (None if on_samples consumed it)."""
         collected = []
         sink = on_samples if on_samples is not None else collected.append
-        run = SelfPlayRunner(self, temp, seed0, first_game_id, game_id_stride, n_games_total, sink)
+        run = SelfPlayRunner(self, temp, seed0, first_game_id, game_id_stride, n_games_total, sink,
+                             pipelined=pipelined)
         run.start()
         while run.games_done < n_games_total and (max_moves is None or run.steps < max_moves):
             run.step()
+        run.finish()
         samples = None
         if collected:
             samples = {k: np.concatenate([c[k] for c in collected]) for k in collected[0]}
@@ -216,13 +254,19 @@ class SelfPlayRunner:
     """Keeps the B slots of an engine busy: every step() is one move for every live game
     (MCTSPlayer.get_action + the per-move part of Game.start_self_play); finished games are
     drained and their slots restarted with the next game id until `total` games have been
-    started (total=None: without limit)."""
+    started (total=None: without limit).
+
+    pipelined=True uses the engine's azg_selfplay_* calls: finished slots restart on the device
+    and the next search is already running while the host handles the finished games, whose
+    samples reach on_samples one step later (call finish() for the last ones).  The games
+    played are the same either way; which slot plays which game may differ."""
 
     def __init__(self, engine, temp=1.0, seed0=0, first_game_id=0, game_id_stride=1, total=None,
-                 on_samples=None, device_samples=False):
+                 on_samples=None, device_samples=False, pipelined=False):
         self.e, self.temp, self.seed0 = engine, float(temp), int(seed0)
         self.first, self.stride, self.total = int(first_game_id), int(game_id_stride), total
         self.on_samples, self.device_samples = on_samples, device_samples
+        self.pipelined, self._running = bool(pipelined), False
         B = engine.B
         self.ids = np.zeros(B, dtype=np.int64)
         self.seeds = np.zeros(B, dtype=np.uint32)
@@ -245,11 +289,34 @@ class SelfPlayRunner:
             self.e.reset_games(seeds=self.seeds, mask=mask, game_ids=self.ids)
 
     def start(self):
-        self._assign(range(self.e.B))
+        if self.pipelined:
+            self.e.selfplay_begin(self.temp, self.seed0, self.first, self.stride, self.total)
+            self._running = True
+        else:
+            self._assign(range(self.e.B))
+
+    def _deliver(self, n):
+        if n:
+            out = self.e.selfplay_fetch(n, device=self.device_samples)
+            self.plies_done += n
+            if self.on_samples is not None:
+                self.on_samples(out)
+
+    def finish(self):
+        """Pipelined mode: wait for the work in flight and deliver the last samples."""
+        if self._running:
+            self._running = False
+            self._deliver(self.e.selfplay_end())
 
     def step(self):
         """One move for every live slot; returns (games finished, samples drained)."""
         e = self.e
+        if self.pipelined:
+            nfin, ready = e.selfplay_step()
+            self.steps += 1
+            self.games_done += nfin
+            self._deliver(ready)
+            return nfin, ready
         e.search()
         e.sample_and_advance(self.temp, want_pi=False)
         self.steps += 1

@@ -65,6 +65,8 @@ def main():
     ap.add_argument("--n-in-row", type=int, default=5)
     ap.add_argument("--playouts", type=int, default=400)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--host-refill", action="store_true",
+                    help="restart finished slots from the host between steps instead of the pipelined azg_selfplay_* calls")
     ap.add_argument("--cnn", choices=["f16x3", "f32"], default="f16x3",
                     help="conv arithmetic: split-f16 MFMA (three products, f32 accumulate) or f32-input MFMA")
     args = ap.parse_args()
@@ -94,7 +96,7 @@ def main():
     eng.set_weights(params)
     drained = []
     run = SelfPlayRunner(eng, temp=1.0, seed0=0, first_game_id=rank, game_id_stride=world,
-                         total=None, on_samples=drained.append, device_samples=True)
+                         total=None, on_samples=drained.append, device_samples=True, pipelined=not args.host_refill)
     run.start()
     for _ in range(args.warmup):
         run.step()
@@ -123,6 +125,7 @@ def main():
     if use_dist:
         dist.barrier()
     dt = time.perf_counter() - t0
+    run.finish()
     games, plies = run.games_done - g0, run.plies_done - p0
     launches, kernel_ms, evals = eng.profile()
 

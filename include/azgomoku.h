@@ -132,6 +132,31 @@ int azg_states(azg_handle *h, float *out);
 int azg_drain_samples(azg_handle *h, int max_samples, float *states, double *pi, float *z,
                       int64_t *game_id, int32_t *ply, int *n_out);
 
+/* Pipelined self-play: the loop of train.py:146 (collect_selfplay_data calling
+ * Game.start_self_play, game.py:360-416) for all slots, with no host round trip between
+ * a move step and the next search.  Game number k of the run (k = 0, 1, ...) has id
+ * first_id + k*stride and plays exactly the game
+ *   np.random.seed(seed0 + id); game.start_self_play(player, temp)
+ * would play with the same weights; games are handed to slots in the order slots free
+ * up.  total < 0: no limit, else no game with k >= total is started.
+ *
+ * azg_selfplay_begin resets every slot, starts games k = 0..n_games-1 and enqueues
+ * the first search.  azg_selfplay_step finishes one move for every live slot
+ * (azg_sample_and_advance semantics), restarts finished slots on the device and
+ * enqueues the next search before it waits for anything; it reports how many games
+ * ended in this step and how many samples of EARLIER finished games are now ready.
+ * azg_selfplay_fetch copies those samples (layout as azg_drain_samples; host or device
+ * pointers, any may be NULL) and must be called before the next step, or the samples
+ * are dropped.  azg_selfplay_end waits for the work in flight, makes the samples of the
+ * last finished games ready for a final fetch and returns the handle to the
+ * synchronous calls (which fail with AZG_ESTATE in between). */
+int azg_selfplay_begin(azg_handle *h, double temp, uint32_t seed0, int64_t first_id,
+                       int64_t stride, int64_t total);
+int azg_selfplay_step(azg_handle *h, int *games_finished, int *samples_ready);
+int azg_selfplay_fetch(azg_handle *h, float *states, double *pi, float *z,
+                       int64_t *game_id, int32_t *ply);
+int azg_selfplay_end(azg_handle *h, int *samples_ready);
+
 /* PolicyValueNet.policy_value (policy_value_net_pytorch.py:80-94): states f32
  * [n,4,N,N] -> probs f32 [n,S] (exp of the log-softmax), values f32 [n].  Host or
  * device pointers. */

@@ -205,14 +205,26 @@ def test_net_search_bit_exact_vs_oracle_with_gpu_priors(az, oracle, cnn_mode):
         ev.close()
 
 
-def test_batched_games_are_independent_of_batching(az, oracle):
+@pytest.mark.parametrize("pipelined", [False, True], ids=["host-refill", "device-refill"])
+def test_batched_games_are_independent_of_batching(az, oracle, pipelined):
     """Many games in flight: each slot's game must equal the oracle's game for that seed,
-    whatever slot or batch it ran in (hash priors; bit-exact moves and visit counts)."""
+    whatever slot or batch it ran in (hash priors; bit-exact moves and visit counts), both with
+    slots restarted by the host between steps and with the pipelined azg_selfplay_* calls that
+    restart them on the device while the next search is already enqueued."""
     n, k, npo = 8, 5, 64
     eng = az.SelfPlayEngine(n, k, npo, 37, prior_mode=az.PRIOR_HASH)
-    res = eng.play_games(60, temp=1.0, seed0=1000)
+    res = eng.play_games(60, temp=1.0, seed0=1000, pipelined=pipelined)
     s = res["samples"]
     assert res["games"] == 60
+    assert sorted(set(s["game_id"].tolist())) == list(range(60))
+    assert res["plies"] == len(s["z"])
+    if pipelined:
+        with pytest.raises(az._lib.AzgError):
+            eng.selfplay_step()                              # not between begin and end
+        eng.selfplay_begin(total=3)
+        with pytest.raises(az._lib.AzgError):
+            eng.sample_and_advance()                         # synchronous calls are locked out
+        eng.selfplay_end()
     for gid in (0, 1, 17, 36, 37, 59):
         r = oracle.self_play(n, k, "hash", 5, npo, 1.0, 1000 + gid)
         sel = np.nonzero(s["game_id"] == gid)[0]
