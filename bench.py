@@ -48,11 +48,17 @@ def cpu_baseline(n, k, n_playout, params_np, seconds_hint=25.0):
     t0 = time.time()
     total_plies, plies, _ = az_oracle.self_play_many(n, k, net, 5.0, n_playout, 1.0, 0, threads, threads)
     dt = time.time() - t0
+    # the same port on one core: one game (seed 0)
+    t1 = time.time()
+    plies1, _, _ = az_oracle.self_play_many(n, k, net, 5.0, n_playout, 1.0, 0, 1, 1)
+    dt1 = time.time() - t1
     return {"value": threads / dt, "unit": "games/s", "cores": threads, "kind": "port",
             "sample": "%d games (one per thread, seeds 0..%d), %d plies, %d playouts in %.1f s; "
                       "C restatement of the reference's Python path, float32 net"
                       % (threads, threads - 1, total_plies, total_plies * n_playout, dt),
-            "playouts_per_s": total_plies * n_playout / dt}
+            "playouts_per_s": total_plies * n_playout / dt,
+            "single_core": {"value": 1.0 / dt1, "unit": "games/s", "cores": 1,
+                            "sample": "1 game (seed 0), %d plies in %.1f s" % (plies1, dt1)}}
 
 
 def main():
@@ -169,6 +175,14 @@ def main():
                          "launches": launches, "avg_launch_ms": kernel_ms / launches if launches else None,
                          "flop_per_leaf_eval": flop, "leaf_evals_per_launch": evals_per_gpu / launches if launches else None},
         }
+        # the tree / board side of the same launch against the HBM roof: algorithmic bytes per
+        # playout (select reads, expand writes, backup, board copy, planes, net output) x playouts
+        tree_bytes = {8: 3.7e3, 15: 14.4e3}.get(n)
+        if tree_bytes and kernel_ms > 0:
+            hbm = tree_bytes * (args.playouts * args.games) / (kernel_ms / launches * 1e-3) / 1e9
+            out["roofline_tree_side"] = {"bound": "hbm", "achieved": hbm, "peak": 8000.0, "unit": "GB/s", "frac": hbm / 8000.0,
+                                         "note": "same kernel; %.1f KB of tree/board traffic per playout, latency-bound "
+                                                 "pointer chasing inside the fused launch" % (tree_bytes / 1e3)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(n, k, args.playouts, [p.cpu().numpy() for p in params])
         print(json.dumps(out))
