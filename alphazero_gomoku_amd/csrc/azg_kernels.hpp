@@ -526,6 +526,44 @@ __global__ void drain_kernel(DevState st, int n, const int *map_g, const int *ma
     }
 }
 
+// TrainPipeline.get_equi_data (train.py:116-135): the 8 dihedral images of every (state, pi, z)
+// tuple, in the reference's order: for i = 1..4 the counter-clockwise rotation by i*90 degrees,
+// then that rotation mirrored left-right.  States are stored row-flipped (game.py:115), which is
+// why pi is flipped up-down before the rotation and again after it.  One block per output tuple.
+__device__ inline void rot90_src(int i, int N, int r, int c, int &sr, int &sc)
+{
+    // np.rot90(m, i)[r][c] == m[sr][sc]
+    switch (i & 3) {
+    case 1: sr = c; sc = N - 1 - r; break;
+    case 2: sr = N - 1 - r; sc = N - 1 - c; break;
+    case 3: sr = N - 1 - c; sc = r; break;
+    default: sr = r; sc = c; break;
+    }
+}
+
+__global__ void equi_kernel(int N, int n, const float *states, const double *pi, const float *z, float *states_out,
+                            double *pi_out, float *z_out)
+{
+    const int o = blockIdx.x;
+    if (o >= 8 * n) return;
+    const int src = o >> 3, v = o & 7, i = (v >> 1) + 1, flip = v & 1;
+    const int S = N * N;
+    for (int idx = threadIdx.x; idx < 4 * S; idx += blockDim.x) {
+        const int ch = idx / S, rem = idx - ch * S, r = rem / N, c = rem - r * N;
+        int sr, sc;
+        rot90_src(i, N, r, flip ? N - 1 - c : c, sr, sc);
+        states_out[(size_t)o * 4 * S + idx] = states[((size_t)src * 4 + ch) * S + sr * N + sc];
+    }
+    for (int idx = threadIdx.x; idx < S; idx += blockDim.x) {
+        const int r = idx / N, c = idx - r * N;
+        // out = flipud(X); X = fliplr(R) or R; R = rot90(flipud(P), i)
+        int sr, sc;
+        rot90_src(i, N, N - 1 - r, flip ? N - 1 - c : c, sr, sc);
+        pi_out[(size_t)o * S + idx] = pi[(size_t)src * S + (N - 1 - sr) * N + sc];
+    }
+    if (threadIdx.x == 0) z_out[o] = z[src];
+}
+
 // Stateless Board.do_move + game_end + current_state for n boards, one per wave.
 __global__ __launch_bounds__(256) void board_step_kernel(int N, int nrow, int n, u64 *stones, int *ply,
                                                          int *last, const int *moves, const int *player,

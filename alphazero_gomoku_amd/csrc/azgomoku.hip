@@ -1006,6 +1006,36 @@ extern "C" int azg_selfplay_end(azg_handle *h, int *samples_ready)
     return rc;
 }
 
+extern "C" int azg_equi_data(azg_handle *h, int n, const float *states, const double *pi, const float *z,
+                             float *states_out, double *pi_out, float *z_out)
+{
+    if (!h || !states || !pi || !z || !states_out || !pi_out || !z_out || n < 0) return fail(h, AZG_EINVAL, "bad argument");
+    if (n == 0) return AZG_OK;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    const int S = h->st.S;
+    // staging on the copy-free side: inputs and outputs may be host or device memory
+    void *ds, *dp, *dz, *os, *op, *oz;
+    int rc;
+    hipStream_t cs = h->stream;
+    if ((rc = scratch_get(h, 26, (size_t)n * 4 * S * sizeof(float), &ds))) return rc;
+    if ((rc = scratch_get(h, 27, (size_t)n * S * sizeof(double), &dp))) return rc;
+    if ((rc = scratch_get(h, 28, (size_t)n * sizeof(float), &dz))) return rc;
+    if ((rc = scratch_get(h, 29, (size_t)8 * n * 4 * S * sizeof(float), &os))) return rc;
+    if ((rc = scratch_get(h, 30, (size_t)8 * n * S * sizeof(double), &op))) return rc;
+    if ((rc = scratch_get(h, 31, (size_t)8 * n * sizeof(float), &oz))) return rc;
+    HIPCHK(h, hipMemcpyAsync(ds, states, (size_t)n * 4 * S * sizeof(float), hipMemcpyDefault, cs));
+    HIPCHK(h, hipMemcpyAsync(dp, pi, (size_t)n * S * sizeof(double), hipMemcpyDefault, cs));
+    HIPCHK(h, hipMemcpyAsync(dz, z, (size_t)n * sizeof(float), hipMemcpyDefault, cs));
+    hipLaunchKernelGGL(equi_kernel, dim3(8 * n), dim3(256), 0, cs, h->st.N, n, (const float *)ds, (const double *)dp,
+                       (const float *)dz, (float *)os, (double *)op, (float *)oz);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipMemcpyAsync(states_out, os, (size_t)8 * n * 4 * S * sizeof(float), hipMemcpyDefault, cs));
+    HIPCHK(h, hipMemcpyAsync(pi_out, op, (size_t)8 * n * S * sizeof(double), hipMemcpyDefault, cs));
+    HIPCHK(h, hipMemcpyAsync(z_out, oz, (size_t)8 * n * sizeof(float), hipMemcpyDefault, cs));
+    HIPCHK(h, hipStreamSynchronize(cs));
+    return AZG_OK;
+}
+
 // Diagnostic builds (-DAZG_STAMPS) only: 32 summed phase counters, then per workgroup of the
 // last search launch (loop time in 100 MHz ticks, hardware id) for the first 2048 workgroups.
 extern "C" int azg_debug_stamps(azg_handle *h, long long out[kStampWords])

@@ -171,6 +171,14 @@ int azg_board_step_batch(azg_handle *h, int n, uint64_t *stones, int32_t *ply,
                          int32_t *last_move, const int32_t *moves, const int32_t *player,
                          uint8_t *ended, int8_t *winner, float *planes);
 
+/* TrainPipeline.get_equi_data (train.py:116-135): the 8 rotated / mirrored images of n
+ * (state, pi, z) tuples (layout of azg_drain_samples), tuple i giving outputs 8i..8i+7
+ * in the reference's order (rotation by 90, its left-right mirror, rotation by 180, ...).
+ * Outputs hold 8n tuples; all pointers host or device.  Not valid while a pipelined
+ * self-play search is in flight on the handle (it would wait for it). */
+int azg_equi_data(azg_handle *h, int n, const float *states, const double *pi, const float *z,
+                  float *states_out, double *pi_out, float *z_out);
+
 /* Timing of the search kernel, measured with HIP events on the handle's stream:
  * number of launches since the last call, summed milliseconds, and summed leaf
  * evaluations (playouts that reached the CNN).  Resets the counters. */

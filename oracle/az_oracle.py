@@ -268,3 +268,19 @@ class OracleRng:
         out = np.zeros(k)
         lib().azo_rng_dirichlet(self.buf, float(alpha), int(k), out.ctypes.data_as(C.POINTER(C.c_double)))
         return out
+
+
+def equi_data(play_data, board_height, board_width):
+    """TrainPipeline.get_equi_data (train.py:116-135) restated with the same numpy calls.
+    train.py itself cannot be imported here (it imports the Keras net at module level), so this
+    restatement is pinned only by reading the reference: parity unpinned by a reference run."""
+    extend_data = []
+    for state, mcts_prob, winner in play_data:
+        for i in [1, 2, 3, 4]:
+            equi_state = np.array([np.rot90(s, i) for s in state])
+            equi_mcts_prob = np.rot90(np.flipud(mcts_prob.reshape(board_height, board_width)), i)
+            extend_data.append((equi_state, np.flipud(equi_mcts_prob).flatten(), winner))
+            equi_state = np.array([np.fliplr(s) for s in equi_state])
+            equi_mcts_prob = np.fliplr(equi_mcts_prob)
+            extend_data.append((equi_state, np.flipud(equi_mcts_prob).flatten(), winner))
+    return extend_data

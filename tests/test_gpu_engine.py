@@ -321,3 +321,26 @@ def test_policy_value_net_surface(az, oracle):
     for gid, states, mcts_probs, z in out:
         assert states.shape[1:] == (4, n, n) and mcts_probs.shape == (len(z), n * n)
         assert set(np.unique(z)).issubset({-1.0, 0.0, 1.0})
+
+
+def test_equi_data_kernel_matches_fixture(az):
+    """azg_equi_data / get_equi_data (train.py:116-135) on the GPU: bit-exact permutation of the
+    inputs, against the committed fixture, for 6x6, 8x8 and 15x15; numpy and torch entry."""
+    import torch
+    from alphazero_gomoku_amd.train_data import equi_data_arrays, get_equi_data
+    d = load("g6_equi.npz")
+    for n in (6, 8, 15):
+        eng = az.SelfPlayEngine(n, 4, 1, 1, prior_mode=az.PRIOR_HASH)
+        states, pi, z = d["states_%d" % n], d["pi_%d" % n], d["z_%d" % n]
+        so, po, zo = equi_data_arrays(eng, states, pi, z)
+        assert np.array_equal(so, d["ext_states_%d" % n])
+        assert np.array_equal(po, d["ext_pi_%d" % n])
+        assert np.array_equal(zo, d["ext_z_%d" % n])
+        dev = torch.device("cuda", 0)
+        st, pt, zt = (torch.from_numpy(a).to(dev) for a in (states, pi, z))
+        so2, po2, zo2 = equi_data_arrays(eng, st, pt, zt)
+        assert np.array_equal(so2.cpu().numpy(), so) and np.array_equal(po2.cpu().numpy(), po)
+        ext = get_equi_data(eng, [(states[i], pi[i], z[i]) for i in range(len(z))])
+        assert len(ext) == 8 * len(z) and np.array_equal(ext[9][0], so[9]) and np.array_equal(ext[9][1], po[9])
+        assert get_equi_data(eng, []) == []
+        eng.close()

@@ -108,3 +108,28 @@ def test_sample_gather_two_ranks_gloo():
         assert z == exp_z and tuple(pishape) == (8, 4)
         assert gid == [0, 2, 4, 1, 3, 5, 7, 9]
     assert res[0][4] == (0, 2, 4) and res[1][4] == (1, 2, 3)
+
+
+def test_replay_buffer_matches_deque_and_random_sample():
+    """ReplayBuffer against collections.deque(maxlen) + random.sample (train.py:82,155,167)."""
+    import collections
+    import random
+    from alphazero_gomoku_amd.train_data import ReplayBuffer
+    n = 6
+    rng = np.random.RandomState(3)
+    buf, ref = ReplayBuffer(50, n), collections.deque(maxlen=50)
+    for _ in range(7):
+        k = int(rng.randint(1, 20))
+        st = rng.rand(k, 4, n, n).astype(np.float32)
+        pi = rng.rand(k, n * n)
+        z = rng.choice([-1.0, 1.0], size=k).astype(np.float32)
+        buf.extend(st, pi, z)
+        ref.extend([(st[i], pi[i], z[i]) for i in range(k)])
+        assert len(buf) == len(ref)
+        m = min(8, len(ref))
+        random.seed(11)
+        want = random.sample(ref, m)
+        random.seed(11)
+        s2, p2, z2 = buf.sample(m)
+        for i in range(m):
+            assert np.array_equal(s2[i], want[i][0]) and np.array_equal(p2[i], want[i][1]) and z2[i] == want[i][2]

@@ -149,3 +149,17 @@ def test_config1_game_with_net(oracle):
     assert np.array_equal(r["visits"][0], g["visits"][0])
     same = sum(int(a == b) for a, b in zip(r["moves"], g["moves"]))
     assert same >= 1
+
+
+def test_equi_data_restatement_matches_fixture(oracle):
+    """get_equi_data (train.py:116-135): the oracle's numpy restatement against the fixture built
+    from explicit index loops (train.py itself is not importable here: parity unpinned by a
+    reference run)."""
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "g6_equi.npz"))
+    for n in (6, 8, 15):
+        states, pi, z = d["states_%d" % n], d["pi_%d" % n], d["z_%d" % n]
+        ext = oracle.equi_data([(states[i], pi[i], z[i]) for i in range(len(z))], n, n)
+        assert len(ext) == 8 * len(z)
+        assert np.array_equal(np.stack([e[0] for e in ext]), d["ext_states_%d" % n])
+        assert np.array_equal(np.stack([e[1] for e in ext]), d["ext_pi_%d" % n])
+        assert np.array_equal(np.asarray([e[2] for e in ext], dtype=np.float32), d["ext_z_%d" % n])

@@ -392,7 +392,61 @@ def gen_rng():
     print("g5_rng written")
 
 
+# ---------------------------------------------------------------- G6 augmentation
+def gen_equi():
+    """train.py cannot be imported (Keras import at module level), so nothing here is a run of
+    the reference.  The expected values are built from the definition of the 8 images by
+    explicit index loops and must agree with oracle.az_oracle.equi_data, which restates
+    train.py:116-135 with the reference's own numpy calls."""
+    sys.path.insert(0, ROOT)
+    from oracle import az_oracle
+
+    def image(m, i, flip):
+        # counter-clockwise rotation by i*90 degrees, then optional left-right mirror
+        n = m.shape[0]
+        r = m
+        for _ in range(i % 4):
+            q = np.empty_like(r)
+            for a in range(n):
+                for b in range(n):
+                    q[a][b] = r[b][n - 1 - a]
+            r = q
+        if flip:
+            r = r[:, ::-1]
+        return r
+
+    out = {}
+    rng = np.random.RandomState(7)
+    for n in (6, 8, 15):
+        cnt = 5
+        states = (rng.rand(cnt, 4, n, n) < 0.3).astype(np.float32)
+        pi = rng.rand(cnt, n * n)
+        pi /= pi.sum(axis=1, keepdims=True)
+        z = rng.choice([-1.0, 0.0, 1.0], size=cnt).astype(np.float32)
+        ext = []
+        for t in range(cnt):
+            for i in (1, 2, 3, 4):
+                for flip in (False, True):
+                    st = np.stack([image(states[t][c], i, flip) for c in range(4)])
+                    # pi lives on the un-flipped board; states are stored row-flipped
+                    pm = image(pi[t].reshape(n, n)[::-1], i, flip)[::-1].reshape(-1)
+                    ext.append((st, pm, z[t]))
+        chk = az_oracle.equi_data([(states[i], pi[i], z[i]) for i in range(cnt)], n, n)
+        assert len(chk) == len(ext)
+        for a, b in zip(ext, chk):
+            assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2] == b[2]
+        out["states_%d" % n], out["pi_%d" % n], out["z_%d" % n] = states, pi, z
+        out["ext_states_%d" % n] = np.stack([e[0] for e in ext]).astype(np.float32)
+        out["ext_pi_%d" % n] = np.stack([e[1] for e in ext])
+        out["ext_z_%d" % n] = np.asarray([e[2] for e in ext], dtype=np.float32)
+    np.savez_compressed(os.path.join(OUT, "g6_equi.npz"), **out)
+    print("g6_equi written")
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "equi":
+        gen_equi()
+        sys.exit(0)
     check_kats()
     check_spy_equivalence()
     gen_rules()
@@ -400,4 +454,5 @@ if __name__ == "__main__":
     gen_rng()
     gen_cnn()
     gen_games(helpers.make_params(6, seed=106))
+    gen_equi()
     print("done ->", OUT)
