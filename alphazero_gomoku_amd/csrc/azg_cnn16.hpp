@@ -216,48 +216,90 @@ __device__ inline void conv3x3_f16(const half8 *wp, WRing<RING> &ring, const cha
         if (sub * PT + i < G::NT) epi(i, sub * PT + i, acc[i], prow[i], ctx);   // wave-uniform: epilogues may use MFMA
 }
 
+// One group of 32-output tiles of a fully connected layer for one wave: NTG tiles, the wave's
+// KW k-steps of each.  Units (k-step, tile) stream through a ring of RU register pairs.
+template <int NTG, int KW>
+struct FcRing {
+    static constexpr int NU = NTG * KW;
+    static constexpr int RU = NU < 12 ? NU : 12;
+    half8 ah[RU], al[RU];
+};
+
+// w: this lane's entry of tile 0 / k-step 0 of the group; tiles are ks_total k-steps apart.
+template <int NTG, int KW>
+__device__ inline gptr<half8> fc16_src(gptr<half8> w, int ks_total, int u)
+{
+    const int kk = u / NTG, i = u - kk * NTG;
+    return w + ((size_t)i * ks_total + kk) * 128;
+}
+
+template <int NTG, int KW>
+__device__ inline void fc16_preload(gptr<half8> w, int ks_total, FcRing<NTG, KW> &r)
+{
+#pragma unroll
+    for (int u = 0; u < FcRing<NTG, KW>::RU; u++) {
+        const gptr<half8> s = fc16_src<NTG, KW>(w, ks_total, u);
+        r.ah[u] = s[0]; r.al[u] = s[1];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// x is the A operand (row = leaf) and W the B operand (column = output), so a lane of the lower
+// half-wave ends up with one output's value for every leaf in accumulator registers 0 .. T-1.
+// xi: this lane's 16 bytes of the hi image at the wave's first k-step; lo image xlo_off further.
+template <int T, int NTG, int KW>
+__device__ inline void fc16_run(gptr<half8> w, int ks_total, FcRing<NTG, KW> &r, const char *xi, int xlo_off,
+                                bool leaf_lane, float *out /* + (first output of the group) * T */, int half, int n)
+{
+    using R = FcRing<NTG, KW>;
+    const half8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    const f32x16 zacc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    f32x16 acc[NTG];
+    half8 xh = z8, xl = z8;
+#pragma unroll
+    for (int u = 0; u < R::NU; u++) {
+        const int kk = u / NTG, i = u - kk * NTG;
+        if (i == 0) {
+            xh = *reinterpret_cast<const half8 *>(xi + kk * 32);
+            xl = *reinterpret_cast<const half8 *>(xi + kk * 32 + xlo_off);
+            if (!leaf_lane) { xh = z8; xl = z8; }
+        }
+        const half8 wa = r.ah[u % R::RU], wl = r.al[u % R::RU];
+        if (u + R::RU < R::NU) {
+            const gptr<half8> s = fc16_src<NTG, KW>(w, ks_total, u + R::RU);
+            r.ah[u % R::RU] = s[0]; r.al[u % R::RU] = s[1];
+        }
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, wa, kk == 0 ? zacc : acc[i], 0, 0, 0);
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, wl, acc[i], 0, 0, 0);
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xl, wa, acc[i], 0, 0, 0);
+    }
+    if (half == 0) {
+#pragma unroll
+        for (int i = 0; i < NTG; i++)
+#pragma unroll
+            for (int t = 0; t < T; t++) out[(i * 32 + n) * T + t] = acc[i][t];
+    }
+}
+
 // Everything after conv3 for the split-f16 path: head outputs (bias + the four channel-tile
 // partials, ReLU) written as half pairs, both fully connected layers on the matrix cores,
 // softmax and tanh.  A wave takes k-steps [wave*KW, (wave+1)*KW) of every 32-output tile; the
-// four partial sums per output meet in LDS and are added in a fixed order.  All A operands of
-// a wave (or the first RING of them) are requested before the head outputs are formed, so the
-// L2 latency of the weight stream overlaps that stage.
+// four partial sums per output meet in LDS and are added in a fixed order.  The first weights
+// of both layers are requested before the head outputs are formed, so the L2 latency of the
+// weight stream overlaps that stage.
 template <class G>
 __device__ inline void cnn16_tail(const NetWeights &nw, float *lds, int tid, Prof &prof)
 {
     char *ldb = reinterpret_cast<char *>(lds);
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int half = lane >> 5, n = lane & 31;
-    constexpr int NUP = G::OTP * G::KWP, NU = NUP + 2 * G::KWV;     // (k-step, tile) units per wave
-    constexpr int RING = NU < 12 ? NU : 12;
-
-    struct Unit { int fc, grp, kk, tile, ntile, last; };
-    auto unit = [](int u) {
-        Unit q;
-        if (u < NUP) {
-            q.fc = 0; q.grp = u / (G::KWP * G::OC);
-            const int rem = u - q.grp * G::KWP * G::OC;
-            q.kk = rem / G::OC; q.tile = rem - q.kk * G::OC; q.ntile = G::OC;
-            q.last = q.kk == G::KWP - 1 && q.tile == G::OC - 1;
-        } else {
-            const int v = u - NUP;
-            q.fc = 1; q.grp = 0; q.kk = v / 2; q.tile = v - 2 * q.kk; q.ntile = 2;
-            q.last = q.kk == G::KWV - 1 && q.tile == 1;
-        }
-        return q;
-    };
-    const gptr<half8> wp[2] = {as_global(reinterpret_cast<const half8 *>(nw.wfc16[0])),
-                               as_global(reinterpret_cast<const half8 *>(nw.wfc16[1]))};
-    auto wsrc = [&](int u) {
-        const Unit q = unit(u);
-        const int kw = q.fc ? G::KWV : G::KWP;
-        const int ot = q.grp * G::OC + q.tile, ks = wave * kw + q.kk;
-        return wp[q.fc] + (((size_t)ot * (4 * kw) + ks) * 64 + lane) * 2;
-    };
-    half8 ah[RING], al[RING];
-#pragma unroll
-    for (int u = 0; u < RING; u++) { const gptr<half8> s = wsrc(u); ah[u] = s[0]; al[u] = s[1]; }
-    __builtin_amdgcn_sched_barrier(0);
+    constexpr int NGP = G::OTP / G::OC;                    // accumulator groups of act_fc1
+    const gptr<half8> wpol = as_global(reinterpret_cast<const half8 *>(nw.wfc16[0])) + ((size_t)wave * G::KWP * 64 + lane) * 2;
+    const gptr<half8> wval = as_global(reinterpret_cast<const half8 *>(nw.wfc16[1])) + ((size_t)wave * G::KWV * 64 + lane) * 2;
+    FcRing<G::OC, G::KWP> rpol;
+    FcRing<2, G::KWV> rval;
+    fc16_preload<G::OC, G::KWP>(wpol, 4 * G::KWP, rpol);
+    fc16_preload<2, G::KWV>(wval, 4 * G::KWV, rval);
 
     // ---- head outputs, flattened [c][row][col] per head like the reference's view(-1, ...)
     {
@@ -318,44 +360,19 @@ __device__ inline void cnn16_tail(const NetWeights &nw, float *lds, int tid, Pro
 
     // ---- act_fc1 and val_fc1
     {
-        const half8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
         const int leafc = n < G::T ? n : 0;
-        f32x16 acc[G::OC];
-        half8 xh = z8, xl = z8;
-#pragma unroll
-        for (int u = 0; u < NU; u++) {
-            const Unit q = unit(u);
-            const int kw = q.fc ? G::KWV : G::KWP, kp = q.fc ? G::KPV : G::KPP;
-            if (q.tile == 0) {
-                const char *xi = ldb + G::X_OFF * 4 + (q.fc ? 2 * G::T * G::KPP * 2 : 0)
-                                 + (leafc * kp + (wave * kw + q.kk) * 16 + 8 * half) * 2;
-                xh = *reinterpret_cast<const half8 *>(xi);
-                xl = *reinterpret_cast<const half8 *>(xi + G::T * kp * 2);
-                if (n >= G::T) { xh = z8; xl = z8; }
-                if (q.kk == 0) {
-#pragma unroll
-                    for (int i = 0; i < G::OC; i++)
-#pragma unroll
-                        for (int r = 0; r < 16; r++) acc[i][r] = 0.0f;
-                }
-            }
-            const half8 wa = ah[u % RING], wl = al[u % RING];
-            if (u + RING < NU) { const gptr<half8> s = wsrc(u + RING); ah[u % RING] = s[0]; al[u % RING] = s[1]; }
-            // x is the A operand (row = leaf) and W the B operand (column = output), so a
-            // lane of the lower half-wave ends up with one output's value for every leaf in
-            // accumulator registers 0 .. T-1
-            acc[q.tile] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, wa, acc[q.tile], 0, 0, 0);
-            acc[q.tile] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, wl, acc[q.tile], 0, 0, 0);
-            acc[q.tile] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xl, wa, acc[q.tile], 0, 0, 0);
-            if (q.last && half == 0) {
-#pragma unroll
-                for (int i = 0; i < q.ntile; i++) {
-                    const int o = (q.fc ? G::OTP * 32 : q.grp * G::OC * 32) + i * 32 + n;
-#pragma unroll
-                    for (int t = 0; t < G::T; t++) lds[G::PART_OFF + (wave * G::NOUT + o) * G::T + t] = acc[i][t];
-                }
-            }
+        const char *xp = ldb + G::X_OFF * 4 + (leafc * G::KPP + wave * G::KWP * 16 + 8 * half) * 2;
+        const char *xv = ldb + G::X_OFF * 4 + 2 * G::T * G::KPP * 2 + (leafc * G::KPV + wave * G::KWV * 16 + 8 * half) * 2;
+        float *part = lds + G::PART_OFF + wave * G::NOUT * G::T;
+        fc16_run<G::T, G::OC, G::KWP>(wpol, 4 * G::KWP, rpol, xp, G::T * G::KPP * 2, n < G::T, part, half, n);
+        for (int grp = 1; grp < NGP; grp++) {
+            const gptr<half8> wg = wpol + (size_t)grp * G::OC * (4 * G::KWP) * 128;
+            fc16_preload<G::OC, G::KWP>(wg, 4 * G::KWP, rpol);
+            fc16_run<G::T, G::OC, G::KWP>(wg, 4 * G::KWP, rpol, xp, G::T * G::KPP * 2, n < G::T,
+                                          part + grp * G::OC * 32 * G::T, half, n);
         }
+        fc16_run<G::T, 2, G::KWV>(wval, 4 * G::KWV, rval, xv, G::T * G::KPV * 2, n < G::T,
+                                  part + G::OTP * 32 * G::T, half, n);
     }
     __syncthreads();
     prof.mark(8);
