@@ -59,6 +59,7 @@ class PolicyValueNet(object):
         if model_file:
             self.policy_value_net.load_state_dict(torch.load(model_file, map_location=self.device, weights_only=True))
         self.version = 0          # bumped whenever the parameters change
+        self.data_parallel = False   # True: train_step averages gradients over torch.distributed ranks
         self._eval_engine = None
         self._eval_version = -1
 
@@ -116,6 +117,9 @@ class PolicyValueNet(object):
         policy_loss = -torch.mean(torch.sum(p * logp, 1))
         loss = value_loss + policy_loss
         loss.backward()
+        if self.data_parallel and torch.distributed.is_available() and torch.distributed.is_initialized():
+            from .dist import allreduce_gradients
+            allreduce_gradients(self.policy_value_net)       # every rank holds an equal share of the batch
         self.optimizer.step()
         entropy = -torch.mean(torch.sum(torch.exp(logp) * logp, 1))
         self.version += 1

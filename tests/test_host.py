@@ -133,3 +133,68 @@ def test_replay_buffer_matches_deque_and_random_sample():
         s2, p2, z2 = buf.sample(m)
         for i in range(m):
             assert np.array_equal(s2[i], want[i][0]) and np.array_equal(p2[i], want[i][1]) and z2[i] == want[i][2]
+
+
+def _train_batch(n):
+    rng = np.random.RandomState(5)
+    st = (rng.rand(16, 4, n, n) < 0.3).astype(np.float32)
+    pi = rng.rand(16, n * n).astype(np.float32)
+    pi /= pi.sum(axis=1, keepdims=True)
+    z = rng.choice([-1.0, 1.0], size=16).astype(np.float32)
+    return st, pi, z
+
+
+def _train_once(net, opt, st, pi, z, reduce_fn=None):
+    """One optimiser step with the loss of policy_value_net_pytorch.py:117-148."""
+    import torch
+    import torch.nn.functional as F
+    opt.zero_grad()
+    logp, v = net(torch.from_numpy(st))
+    loss = F.mse_loss(v.view(-1), torch.from_numpy(z)) - torch.mean(torch.sum(torch.from_numpy(pi) * logp, 1))
+    loss.backward()
+    if reduce_fn:
+        reduce_fn(net)
+    opt.step()
+    return [p.detach().clone() for p in net.parameters()]
+
+
+def _dp_worker(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+    from alphazero_gomoku_amd import dist as azdist
+    from alphazero_gomoku_amd.net import Net
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(0)
+    net = Net(6, 6)
+    opt = torch.optim.Adam(net.parameters(), lr=2e-3, weight_decay=1e-4)
+    st, pi, z = _train_batch(6)
+    sl = slice(rank * 8, rank * 8 + 8)                     # each rank: its half of the mini-batch
+    out = _train_once(net, opt, st[sl], pi[sl], z[sl], azdist.allreduce_gradients)
+    q.put((rank, [p.numpy() for p in out]))
+    dist.destroy_process_group()
+
+
+def test_data_parallel_train_step_two_ranks_gloo():
+    """Two ranks, half a mini-batch each, gradients averaged with one flat all_reduce: the
+    parameters after the step equal a single-process step on the whole mini-batch."""
+    import torch
+    import torch.multiprocessing as mp
+    from alphazero_gomoku_amd.net import Net
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=180) for _ in range(2)), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+    torch.manual_seed(0)
+    net = Net(6, 6)
+    opt = torch.optim.Adam(net.parameters(), lr=2e-3, weight_decay=1e-4)
+    want = _train_once(net, opt, *_train_batch(6))
+    for a, b, w in zip(res[0][1], res[1][1], want):
+        assert np.array_equal(a, b)
+        np.testing.assert_allclose(a, w.numpy(), rtol=0, atol=2e-6)
