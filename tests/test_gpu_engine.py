@@ -344,3 +344,37 @@ def test_equi_data_kernel_matches_fixture(az):
         assert len(ext) == 8 * len(z) and np.array_equal(ext[9][0], so[9]) and np.array_equal(ext[9][1], po[9])
         assert get_equi_data(eng, []) == []
         eng.close()
+
+
+def test_split_f16_weight_range_is_checked(az):
+    """The split-f16 convolutions hold w * 2^8 in halves: out-of-range weights are rejected
+    with a clear error instead of overflowing; the float32 variant accepts them."""
+    params = helpers.make_params(6, seed=1)
+    params[4] = params[4].copy()
+    params[4].flat[3] = 300.0
+    eng = az.SelfPlayEngine(6, 4, 8, 1, cnn_mode=az._lib.CNN_F16X3)
+    with pytest.raises(az._lib.AzgError) as ei:
+        eng.set_weights(params)
+    assert "AZG_CNN_F32" in str(ei.value)
+    eng.close()
+    eng = az.SelfPlayEngine(6, 4, 8, 1, cnn_mode=az._lib.CNN_F32)
+    eng.set_weights(params)
+    eng.close()
+
+
+def test_pipelined_selfplay_with_fewer_games_than_slots(az, oracle):
+    """azg_selfplay_* with total < n_games: the spare slots stay idle, exactly `total` games are
+    played, each equal to the oracle's game for its seed, with a game-id stride (rank sharding)."""
+    n, k, npo = 6, 4, 32
+    eng = az.SelfPlayEngine(n, k, npo, 8, prior_mode=az.PRIOR_HASH)
+    res = eng.play_games(5, temp=1.0, seed0=40, first_game_id=1, game_id_stride=2, pipelined=True)
+    s = res["samples"]
+    assert res["games"] == 5 and sorted(set(s["game_id"].tolist())) == [1, 3, 5, 7, 9]
+    for gid in (1, 9):
+        r = oracle.self_play(n, k, "hash", 5, npo, 1.0, 40 + gid)
+        sel = np.nonzero(s["game_id"] == gid)[0]
+        sel = sel[np.argsort(s["ply"][sel])]
+        assert len(sel) == len(r["moves"])
+        np.testing.assert_allclose(s["pi"][sel], r["pi"], rtol=0, atol=1e-12)
+        assert np.array_equal(s["z"][sel], r["z"].astype(np.float32))
+    eng.close()
