@@ -59,6 +59,51 @@ __device__ inline TreeView tree_view(const DevState &st, int g, int arena)
 // the reads behind the join of the writing branch.
 __device__ inline void wave_sync() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); }
 
+// Wave-wide reductions on the DPP network (register-to-register lane permutations at VALU rate)
+// instead of ds_bpermute round trips through the LDS crossbar: four steps make every lane of a
+// row of 16 hold the row's result (lane^1, lane^2, mirror within 8, mirror within 16), the four
+// rows are then combined from one lane each.  The result is wave-uniform.
+template <int CTRL>
+__device__ inline int dpp_int(int v)
+{
+    return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xF, 0xF, false);
+}
+template <int CTRL>
+__device__ inline double dpp_f64(double v)
+{
+    const long long b = __double_as_longlong(v);
+    const int lo = dpp_int<CTRL>((int)(b & 0xFFFFFFFFLL)), hi = dpp_int<CTRL>((int)(b >> 32));
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+constexpr int DPP_XOR1 = 0xB1, DPP_XOR2 = 0x4E, DPP_HALF_MIRROR = 0x141, DPP_MIRROR = 0x140;
+
+__device__ inline double lane_value_f64(double v, int lane)
+{
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int)(b & 0xFFFFFFFFLL), lane);
+    const int hi = __builtin_amdgcn_readlane((int)(b >> 32), lane);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+__device__ inline double wave_max_f64(double v)
+{
+    v = fmax(v, dpp_f64<DPP_XOR1>(v));
+    v = fmax(v, dpp_f64<DPP_XOR2>(v));
+    v = fmax(v, dpp_f64<DPP_HALF_MIRROR>(v));
+    v = fmax(v, dpp_f64<DPP_MIRROR>(v));
+    return fmax(fmax(lane_value_f64(v, 0), lane_value_f64(v, 16)), fmax(lane_value_f64(v, 32), lane_value_f64(v, 48)));
+}
+
+__device__ inline int wave_min_i32(int v)
+{
+    v = min(v, dpp_int<DPP_XOR1>(v));
+    v = min(v, dpp_int<DPP_XOR2>(v));
+    v = min(v, dpp_int<DPP_HALF_MIRROR>(v));
+    v = min(v, dpp_int<DPP_MIRROR>(v));
+    return min(min(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
+               min(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
+
 // Outcome of a descent, identical in every lane.
 struct Descent {
     int leaf;        // edge index of the leaf
@@ -146,19 +191,15 @@ __device__ inline Descent wave_select(const DevState &st, const TreeView &t, Gam
             const double s = q + u;
             if (s > best) { best = s; bidx = i; bchild = ch; bn = n; bmeta = mt; }
         }
-        double rs = best;
-        int ri = bidx;
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
-            const double os = __shfl_xor(rs, off);
-            const int oi = __shfl_xor(ri, off);
-            if (os > rs || (os == rs && oi < ri)) { rs = os; ri = oi; }
-        }
+        // first maximum in ascending child order: the wave maximum, then the lowest child index
+        // among the lanes that hold it (a lane already kept its own first maximum)
+        const double rs = wave_max_f64(best);
+        const int ri = wave_min_i32(best == rs ? bidx : 0x7fffffff);
         const int src = ri & 63;
         e = child + ri;
-        child = __shfl(bchild, src);
-        Np = __shfl(bn, src);
-        const unsigned mt = __shfl(bmeta, src);
+        child = __builtin_amdgcn_readlane(bchild, src);
+        Np = __builtin_amdgcn_readlane(bn, src);
+        const unsigned mt = (unsigned)__builtin_amdgcn_readlane((int)bmeta, src);
         K = meta_k(mt);
         const int act = meta_act(mt);
         // Board.do_move (game.py:119-127) on the leaf copy
