@@ -92,7 +92,8 @@ __global__ __launch_bounds__(256, (F16 && MODE == 0 && N <= 8) ? 2 : 1) void sea
         if (active) {
             const TreeView tv = tree_view(st, g, gl->arena);
             d = wave_select(st, tv, gl, lane);
-            term = wave_game_end(gl->leaf_bb, st.N, st.S, st.n_in_row, d.ply, lane);
+            if (st.NW == 1) term = game_end_1w(gl->leaf_bb[0][0], gl->leaf_bb[1][0], st.N, st.S, st.n_in_row, d.ply);
+            else term = wave_game_end(gl->leaf_bb, st.N, st.S, st.n_in_row, d.ply, lane);
             if (lane == 0) { gl->term = term; gl->need_eval = term == 0; }
             n_eval += term == 0;
         }

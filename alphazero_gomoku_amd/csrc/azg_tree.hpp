@@ -158,6 +158,40 @@ __device__ inline int wave_game_end(const u64 (*bb)[MAXW], int N, int S, int nro
     return nstones == S ? 3 : 0;                                 // game.py:167-168
 }
 
+// The same test for boards of at most 64 cells (one word per colour), as whole-board bit
+// operations: bit c of the anchor set is on when cells c, c+d, ..., c+(n-1)d are all the
+// player's and the ray stays on the board (the reference's range tests, game.py:143-157).
+// The reference reports the owner of the lowest anchor over both colours.  All operands are
+// wave-uniform, so every lane computes the same result.
+__device__ inline u64 win_anchors_1w(u64 m, int N, int nrow, u64 right_ok, u64 left_ok, u64 rows_ok)
+{
+    u64 a = m, b = m, d = m, e = m;
+    for (int j = 1; j < nrow; j++) {
+        a &= m >> j;
+        b &= m >> (j * N);
+        d &= m >> (j * (N + 1));
+        e &= m >> (j * (N - 1));
+    }
+    return (a & right_ok) | (b & rows_ok) | (d & right_ok & rows_ok) | (e & left_ok & rows_ok);
+}
+
+__device__ inline int game_end_1w(u64 s1, u64 s2, int N, int S, int nrow, int nstones)
+{
+    if (nstones >= nrow + 2) {                                   // game.py:136-137
+        const u64 row_right = (1ULL << (N - nrow + 1)) - 1ULL;               // w <= N - n
+        const u64 row_left = ((1ULL << N) - 1ULL) & ~((1ULL << (nrow - 1)) - 1ULL);   // w >= n - 1
+        u64 right_ok = 0, left_ok = 0;
+        for (int r = 0; r < N; r++) { right_ok |= row_right << (r * N); left_ok |= row_left << (r * N); }
+        const int nr = (N - nrow + 1) * N;                                   // h <= N - n
+        const u64 rows_ok = nr >= 64 ? ~0ULL : (1ULL << nr) - 1ULL;
+        const u64 w1 = win_anchors_1w(s1, N, nrow, right_ok, left_ok, rows_ok);
+        const u64 w2 = win_anchors_1w(s2, N, nrow, right_ok, left_ok, rows_ok);
+        const u64 any = w1 | w2;
+        if (any) return ((w1 & (any & (~any + 1ULL))) != 0) ? 1 : 2;          // owner of the lowest anchor
+    }
+    return nstones == S ? 3 : 0;                                 // game.py:167-168
+}
+
 // ---------------------------------------------------------------- select
 // Descend from the root to a leaf (mcts_alphaZero.py:122-129).  Lanes hold one child
 // each (four at most on 16x16); the argmax keeps the first maximum in ascending child
