@@ -78,7 +78,11 @@ __global__ __launch_bounds__(256, (F16 && MODE == 0 && N <= 8) ? 2 : 1) void sea
     if (MODE == 0) net_prepare<G, F16>(st.net, smem);
 
     const bool active = tree_wave && gl->live;
-    if (active && lane == 0) gl->arena = st.cur[g];
+    if (active && lane == 0) {
+        gl->arena = st.cur[g];
+        gl->used = st.used[g];
+        gl->root_act = meta_act(tree_view(st, g, st.cur[g]).meta[0]);
+    }
     wave_sync();
     long long n_eval = 0;
     MatrixGate gate;
@@ -145,7 +149,7 @@ __global__ __launch_bounds__(256, (F16 && MODE == 0 && N <= 8) ? 2 : 1) void sea
         prof.mark(10);
     }
     prof.finish();
-    if (active && lane == 0) st.evals[g] += n_eval;
+    if (active && lane == 0) { st.evals[g] += n_eval; st.used[g] = gl->used; }
 }
 
 // ---------------------------------------------------------------- eval_batch

@@ -28,7 +28,11 @@ __device__ inline bool bb_has(const u64 *set, int c) { return (set[c >> 6] >> (c
 struct GameLds {
     u64 root_bb[2][MAXW];
     u64 leaf_bb[2][MAXW];
+    double path_q[MAXS + 1];   // Q of the path's edges as read during the descent
     int path[MAXS + 1];        // edge indices root .. leaf
+    int path_n[MAXS + 1];      // visit counts of the path's edges as read during the descent
+    int used;                  // edges in use in the live arena (DevState::used during a launch)
+    int root_act;              // action stored in the root edge
     int depth;                 // entries in path
     int leaf;                  // edge index of the leaf (= path[depth-1])
     int arena;                 // live arena of the game's tree
@@ -207,10 +211,11 @@ __device__ inline Descent wave_select(const DevState &st, const TreeView &t, Gam
     int child = t.child[0];
     int K = meta_k(t.meta[0]);
     int Np = t.N[0];
-    if (lane == 0) gl->path[0] = 0;
+    const double q0 = t.Q[0];
+    if (lane == 0) { gl->path[0] = 0; gl->path_n[0] = Np; gl->path_q[0] = q0; }
     while (child >= 0) {
         const double sq = sqrt((double)Np);                      // np.sqrt(parent._n_visits)
-        double best = -HUGE_VAL;
+        double best = -HUGE_VAL, bq = 0.0;
         int bidx = 0x7fffffff, bchild = -1, bn = 0;
         unsigned bmeta = 0;
         for (int i = lane; i < K; i += WAVE) {
@@ -223,7 +228,7 @@ __device__ inline Descent wave_select(const DevState &st, const TreeView &t, Gam
             // get_value (:82-83): c_puct * P * sqrt(Np) / (1 + n), left to right, then Q + u
             const double u = ((st.c_puct * (double)p) * sq) / (double)(1 + n);
             const double s = q + u;
-            if (s > best) { best = s; bidx = i; bchild = ch; bn = n; bmeta = mt; }
+            if (s > best) { best = s; bq = q; bidx = i; bchild = ch; bn = n; bmeta = mt; }
         }
         // first maximum in ascending child order: the wave maximum, then the lowest child index
         // among the lanes that hold it (a lane already kept its own first maximum)
@@ -233,6 +238,7 @@ __device__ inline Descent wave_select(const DevState &st, const TreeView &t, Gam
         e = child + ri;
         child = __builtin_amdgcn_readlane(bchild, src);
         Np = __builtin_amdgcn_readlane(bn, src);
+        const double qsel = lane_value_f64(bq, src);
         const unsigned mt = (unsigned)__builtin_amdgcn_readlane((int)bmeta, src);
         K = meta_k(mt);
         const int act = meta_act(mt);
@@ -241,6 +247,8 @@ __device__ inline Descent wave_select(const DevState &st, const TreeView &t, Gam
             const int mover = player_at(gl->first_player, ply);
             gl->leaf_bb[mover - 1][act >> 6] |= 1ULL << (act & 63);
             gl->path[depth] = e;
+            gl->path_n[depth] = Np;
+            gl->path_q[depth] = qsel;
         }
         depth++;
         ply++;
@@ -258,12 +266,12 @@ __device__ inline Descent wave_select(const DevState &st, const TreeView &t, Gam
 // from the provider's per-cell output without renormalisation.  `prior_of(cell)`
 // returns the float32 prior.  Returns false when the arena is full.
 template <typename PriorFn>
-__device__ inline bool wave_expand(const DevState &st, const TreeView &t, const GameLds *gl,
+__device__ inline bool wave_expand(const DevState &st, const TreeView &t, GameLds *gl,
                                    const Descent &d, int g, int lane, PriorFn prior_of)
 {
     const int leaf = d.leaf;
     const int K = st.S - d.ply;
-    const int base = st.used[g];
+    const int base = gl->used;
     if (base + K > st.cap) {
         if (lane == 0) st.err[g] |= 1;
         return false;
@@ -284,10 +292,12 @@ __device__ inline bool wave_expand(const DevState &st, const TreeView &t, const 
         }
         before += __popcll(m);
     }
+    wave_sync();                                   // every lane has read gl->used
     if (lane == 0) {
+        // the leaf's own action is the last move of the descent (the root keeps what it had)
         t.child[leaf] = base;
-        t.meta[leaf] = meta_pack(meta_act(t.meta[leaf]), K);
-        st.used[g] = base + K;
+        t.meta[leaf] = meta_pack(d.depth == 1 ? gl->root_act : d.last, K);
+        gl->used = base + K;
     }
     return true;
 }
@@ -300,10 +310,12 @@ __device__ inline void wave_backup(const TreeView &t, const GameLds *gl, int dep
 {
     const int d = depth;
     for (int j = lane; j < d; j += WAVE) {
+        // N and Q of the path's edges were read by the descent (nothing else writes this tree
+        // during a launch), so the update needs no further loads
         const int e = gl->path[j];
         const double x = ((d - 1 - j) & 1) ? leaf_value : -leaf_value;
-        const int n = t.N[e] + 1;
-        const double q = t.Q[e];
+        const int n = gl->path_n[j] + 1;
+        const double q = gl->path_q[j];
         t.N[e] = n;
         t.Q[e] = q + (1.0 * (x - q)) / (double)n;
     }
