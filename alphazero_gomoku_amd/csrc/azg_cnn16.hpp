@@ -158,6 +158,8 @@ __device__ inline void conv3x3_f16(const half8 *wp, WRing<RING> &ring, const cha
     // of a step never wait for a load of that step.
     const gptr<half8> wrow = conv_wrow<CINP, COUT, RING>(wp, wave, lane);
     half8 (&ah)[RING] = ring.ah, (&al)[RING] = ring.al;
+    // dense phase: take issue priority over the co-resident workgroup's scalar / f64 tree code
+    if (COUT >= 64) __builtin_amdgcn_s_setprio(2);
     // BPF (activation prefetch) costs 8*PT registers; the two-workgroups-per-CU builds drop it
     // and let the other workgroup's waves cover the LDS latency instead.
     constexpr int NB = BPF ? 2 : 1;
@@ -206,6 +208,7 @@ __device__ inline void conv3x3_f16(const half8 *wp, WRing<RING> &ring, const cha
         }
         __builtin_amdgcn_sched_barrier(0);
     }
+    if (COUT >= 64) __builtin_amdgcn_s_setprio(0);
     if (prof) prof->mark(slot);
     // prep() reads what every tile's epilogue needs from LDS once, before the first epilogue
     // store (the compiler must assume a later read could alias such a store and would
