@@ -122,9 +122,10 @@ def main():
         if drained:
             mine = {key: torch.cat([d[key] for d in drained]) for key in ("states", "pi", "z", "game_id", "ply")}
         else:
-            mine = {"states": torch.empty((0, 4, n, n), device=dev), "pi": torch.empty((0, n * n), dtype=torch.float64, device=dev),
+            mine = {"states": torch.empty((0, 4, n, n), dtype=torch.float32, device=dev), "pi": torch.empty((0, n * n), dtype=torch.float64, device=dev),
                     "z": torch.empty(0, device=dev), "game_id": torch.empty(0, dtype=torch.int64, device=dev),
                     "ply": torch.empty(0, dtype=torch.int32, device=dev)}
+        mine["states"] = mine["states"].to(torch.uint8)   # the planes are 0/1: exact, a quarter of the bytes on the links
         allt = azdist.gather_samples(mine)
         gathered = int(allt["z"].shape[0])
     torch.cuda.synchronize()
