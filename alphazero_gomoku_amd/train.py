@@ -1,0 +1,113 @@
+"""TrainPipeline: the self-play / policy-update loop of the reference's train.py
+(train.py:60-214, 278-330) on top of the HIP self-play engine.
+
+What is kept: the constructor's hyper-parameters and their meaning, collect_selfplay_data
+(self-play + 8-fold augmentation into the replay buffer), policy_update (mini-batch from the
+buffer, `epochs` train steps with the KL early stop, the adaptive learning-rate multiplier and the
+explained-variance report) and run().  What differs: games are played `play_batch_size` at a time
+on the GPU instead of one by one; hyper-parameters come as keyword arguments instead of the YAML
+file; the evaluation against the pure-MCTS player (train.py:216-276) is not part of this class.
+With torch.distributed initialised every rank plays its share of the games, all ranks gather all
+tuples, and a policy update is one data-parallel step (each rank its slice of the mini-batch)."""
+import random
+
+import numpy as np
+
+from .board import Board
+from .engine import SelfPlayEngine
+from .game import Game
+from .train_data import ReplayBuffer, equi_data_arrays
+
+
+class TrainPipeline:
+    def __init__(self, board_width=8, board_height=8, n_in_row=5, init_model=None, learn_rate=2e-3,
+                 lr_multiplier=1.0, temp=1.0, n_playout=400, c_puct=5, buffer_size=10000, batch_size=512,
+                 play_batch_size=1, epochs=5, kl_targ=0.02, check_freq=50, game_batch_num=1500,
+                 n_parallel=1024, device=0, seed0=0, policy_value_net=None):
+        from .net import PolicyValueNet
+        self.board_width, self.board_height, self.n_in_row = board_width, board_height, n_in_row
+        self.board = Board(width=board_width, height=board_height, n_in_row=n_in_row)
+        self.game = Game(self.board)
+        self.learn_rate, self.lr_multiplier, self.temp = learn_rate, lr_multiplier, temp
+        self.n_playout, self.c_puct = n_playout, c_puct
+        self.buffer_size, self.batch_size = buffer_size, batch_size
+        self.data_buffer = ReplayBuffer(buffer_size, board_width)            # deque(maxlen) of train.py:82
+        self.play_batch_size, self.epochs, self.kl_targ = play_batch_size, epochs, kl_targ
+        self.check_freq, self.game_batch_num = check_freq, game_batch_num
+        self.policy_value_net = policy_value_net or PolicyValueNet(board_width, board_height, model_file=init_model,
+                                                                   device=device)
+        self.device, self.seed0, self.games_played = device, seed0, 0
+        self.engine = SelfPlayEngine(board_width, n_in_row, n_playout, min(n_parallel, max(1, play_batch_size)),
+                                     c_puct, device=device)
+        self._engine_version = -1
+        self.episode_len = 0
+        self.rank, self.world = 0, 1
+        try:
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized():
+                self.rank, self.world = dist.get_rank(), dist.get_world_size()
+                self.policy_value_net.data_parallel = self.world > 1
+        except ImportError:
+            pass
+
+    # ---- train.py:137-159 --------------------------------------------------------------------
+    def collect_selfplay_data(self, n_games=1):
+        """Play n_games self-play games (ids continue from the previous call; game id g uses the
+        noise stream seeded seed0 + g), augment every tuple 8-fold and extend the replay buffer."""
+        self._engine_version = self.policy_value_net.sync_engine(self.engine, self._engine_version)
+        first = self.games_played + self.rank
+        mine = len(range(first, self.games_played + n_games, self.world))
+        res = self.engine.play_games(mine, temp=self.temp, seed0=self.seed0, first_game_id=first,
+                                     game_id_stride=self.world) if mine else dict(samples=None)
+        self.games_played += n_games
+        s = res["samples"]
+        if s is None:
+            s = dict(states=np.zeros((0, 4, self.board_height, self.board_width), dtype=np.float32),
+                     pi=np.zeros((0, self.board_width * self.board_height)), z=np.zeros(0, dtype=np.float32),
+                     game_id=np.zeros(0, dtype=np.int64), ply=np.zeros(0, dtype=np.int32))
+        if self.world > 1:
+            import torch
+            from . import dist as azdist
+            dev = torch.device("cuda", self.device)
+            allt = azdist.gather_samples({k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in s.items()})
+            s = {k: v.cpu().numpy() for k, v in allt.items()}
+        order = np.lexsort((s["ply"], s["game_id"]))                          # game after game, ply after ply
+        states, pi, z = s["states"][order], s["pi"][order], s["z"][order]
+        self.episode_len = int(len(z))
+        if len(z):
+            self.data_buffer.extend(*equi_data_arrays(self.engine, states, pi, z))
+
+    # ---- train.py:161-214 --------------------------------------------------------------------
+    def policy_update(self):
+        state_batch, mcts_probs_batch, winner_batch = self.data_buffer.sample(self.batch_size)
+        net = self.policy_value_net
+        old_probs, old_v = net.policy_value(state_batch)
+        sl = slice(self.rank, None, self.world)                               # this rank's share of the mini-batch
+        kl, loss, entropy = 0.0, float("nan"), float("nan")
+        for _ in range(self.epochs):
+            loss, entropy = net.train_step(state_batch[sl], mcts_probs_batch[sl], winner_batch[sl],
+                                           self.learn_rate * self.lr_multiplier)
+            new_probs, new_v = net.policy_value(state_batch)
+            kl = float(np.mean(np.sum(old_probs * (np.log(old_probs + 1e-10) - np.log(new_probs + 1e-10)), axis=1)))
+            if kl > self.kl_targ * 4:                                         # early stopping if D_KL diverges badly
+                break
+        if kl > self.kl_targ * 2 and self.lr_multiplier > 0.05:
+            self.lr_multiplier /= 1.5
+        elif kl < self.kl_targ / 2 and self.lr_multiplier < 10:
+            self.lr_multiplier *= 1.5
+        var_z = np.var(np.array(winner_batch))
+        self.explained_var_old = 1 - np.var(np.array(winner_batch) - old_v.flatten()) / var_z if var_z > 0 else float("nan")
+        self.explained_var_new = 1 - np.var(np.array(winner_batch) - new_v.flatten()) / var_z if var_z > 0 else float("nan")
+        self.last_kl = kl
+        return loss, entropy
+
+    # ---- train.py:278-330 (self-play -> update; evaluation left out) ----------------------------
+    def run(self, on_batch=None):
+        for i in range(self.game_batch_num):
+            self.collect_selfplay_data(self.play_batch_size)
+            loss = entropy = None
+            if len(self.data_buffer) > self.batch_size:
+                loss, entropy = self.policy_update()
+            if on_batch is not None:
+                on_batch(i, self.episode_len, loss, entropy)
+        return self.policy_value_net
