@@ -15,7 +15,9 @@ import os
 import sys
 import time
 
-import numpy as np
+os.environ["NCCL_DEBUG"] = "WARN"       # before torch / RCCL load: keeps RCCL's banner off stdout (ONE JSON line)
+
+import numpy as np  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -87,7 +89,19 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        # RCCL writes a banner (version, host name, library path) to stdout when its communicator
+        # comes up; stdout must carry ONE JSON line, so fd 1 points at stderr until that is over
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            dist.barrier()
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_stdout, 1)
+            os.close(saved_stdout)
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
