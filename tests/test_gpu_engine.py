@@ -402,3 +402,24 @@ def test_train_pipeline_two_batches(az):
     v0 = tp.policy_value_net.version
     tp.collect_selfplay_data(1)                               # pushes the updated weights into the engine
     assert tp._engine_version == v0
+
+
+def test_net_driven_games_do_not_depend_on_refill_mode_or_batch_width(az):
+    """CNN-driven self-play (split-f16 MFMA net, two workgroups per CU, matrix-pipe gate): the
+    games are a function of (weights, seed) only -- the same tuples come out with host refill and
+    8 slots as with the pipelined device refill and 5 slots."""
+    n, k, npo = 6, 4, 24
+    params = helpers.make_params(n, seed=9)
+    out = []
+    for slots, pipelined in ((8, False), (5, True)):
+        eng = az.SelfPlayEngine(n, k, npo, slots)
+        eng.set_weights(params)
+        res = eng.play_games(12, temp=1.0, seed0=7, pipelined=pipelined)
+        s = res["samples"]
+        order = np.lexsort((s["ply"], s["game_id"]))
+        out.append({key: s[key][order] for key in s})
+        eng.close()
+    a, b = out
+    assert sorted(set(a["game_id"].tolist())) == list(range(12))
+    for key in ("game_id", "ply", "z", "states", "pi"):
+        assert np.array_equal(a[key], b[key]), key
