@@ -423,3 +423,31 @@ def test_net_driven_games_do_not_depend_on_refill_mode_or_batch_width(az):
     assert sorted(set(a["game_id"].tolist())) == list(range(12))
     for key in ("game_id", "ply", "z", "states", "pi"):
         assert np.array_equal(a[key], b[key]), key
+
+
+@pytest.mark.parametrize("cnn_mode", [0, 1], ids=["f16x3", "f32"])
+def test_reference_c1_game_with_the_cnn(az, cnn_mode):
+    """Configuration C1 end to end: the reference's own 6x6 / 4-in-row / 200-playout self-play
+    game driven by its numpy policy-value net (seed 0, recorded by tools/gen_golden.py) is
+    reproduced move for move and visit count for visit count with the leaf evaluations coming
+    from the HIP CNN (the priors agree to ~1e-8, which never flips a PUCT decision here)."""
+    games = [g for g in load("g3_games.npz")["games"] if g["cb"] not in MODES]
+    assert games, "the fixture holds a net-driven game"
+    for g in games:
+        n, k = int(g["n"]), int(g["k"])
+        eng = az.SelfPlayEngine(n, k, int(g["n_playout"]), 1, float(g["c_puct"]), cnn_mode=cnn_mode)
+        eng.set_weights(helpers.make_params(n, seed=106))
+        eng.reset_games(seeds=np.array([g["seed"]], dtype=np.uint32))
+        for t in range(len(g["moves"])):
+            eng.search()
+            visits, _, _, _ = eng.root_stats()
+            assert np.array_equal(visits[0], g["visits"][t]), t
+            moves, pi = eng.sample_and_advance(float(g["temp"]))
+            assert moves[0] == g["moves"][t], t
+            np.testing.assert_allclose(pi[0], g["pi"][t], rtol=0, atol=1e-12)
+        ended, winner, plies = eng.status()
+        assert ended[0] and winner[0] == g["winner"] and plies[0] == len(g["moves"])
+        s = eng.drain_samples()
+        assert np.array_equal(s["z"], g["z"].astype(np.float32))
+        assert np.array_equal(s["states"], g["states"].astype(np.float32))
+        eng.close()
