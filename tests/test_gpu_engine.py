@@ -427,16 +427,19 @@ def test_net_driven_games_do_not_depend_on_refill_mode_or_batch_width(az):
 
 @pytest.mark.parametrize("cnn_mode", [0, 1], ids=["f16x3", "f32"])
 def test_reference_c1_game_with_the_cnn(az, cnn_mode):
-    """Configuration C1 end to end: the reference's own 6x6 / 4-in-row / 200-playout self-play
-    game driven by its numpy policy-value net (seed 0, recorded by tools/gen_golden.py) is
-    reproduced move for move and visit count for visit count with the leaf evaluations coming
-    from the HIP CNN (the priors agree to ~1e-8, which never flips a PUCT decision here)."""
-    games = [g for g in load("g3_games.npz")["games"] if g["cb"] not in MODES]
-    assert games, "the fixture holds a net-driven game"
-    for g in games:
+    """Configuration C1 end to end, and one game at C2's per-game settings: the reference's own
+    6x6 / 4-in-row / 200-playout and 8x8 / 5-in-row / 400-playout self-play games driven by its
+    numpy policy-value net (recorded by tools/gen_golden.py) are reproduced move for move and
+    visit count for visit count with the leaf evaluations coming from the HIP CNN (the priors
+    agree to ~1e-8, which never flips a PUCT decision in these games)."""
+    games = [(g, 106) for g in load("g3_games.npz")["games"] if g["cb"] not in MODES]
+    # and the benchmark's per-game settings: 8x8 / 5-in-row / 400 playouts
+    games += [(g, int(g["param_seed"])) for g in load("g7_net8.npz")["games"]]
+    assert len(games) >= 2, "the fixtures hold net-driven games"
+    for g, param_seed in games:
         n, k = int(g["n"]), int(g["k"])
         eng = az.SelfPlayEngine(n, k, int(g["n_playout"]), 1, float(g["c_puct"]), cnn_mode=cnn_mode)
-        eng.set_weights(helpers.make_params(n, seed=106))
+        eng.set_weights(helpers.make_params(n, seed=param_seed))
         eng.reset_games(seeds=np.array([g["seed"]], dtype=np.uint32))
         for t in range(len(g["moves"])):
             eng.search()

@@ -163,3 +163,14 @@ def test_equi_data_restatement_matches_fixture(oracle):
         assert np.array_equal(np.stack([e[0] for e in ext]), d["ext_states_%d" % n])
         assert np.array_equal(np.stack([e[1] for e in ext]), d["ext_pi_%d" % n])
         assert np.array_equal(np.asarray([e[2] for e in ext], dtype=np.float32), d["ext_z_%d" % n])
+
+
+def test_config2_game_with_net(oracle):
+    """8x8, 5 in a row, 400 playouts (the benchmark's per-game settings), net-driven game recorded
+    from the reference: the oracle's first search from the empty board must give the reference's
+    visit counts; later plies may part ways (summation order of the two CPU nets differs)."""
+    g = load("g7_net8.npz")["games"][0]
+    net = oracle.OracleNet(8, 8, helpers.make_params(8, seed=int(g["param_seed"])), precise=True)
+    r = oracle.self_play(8, 5, "net", 5, 400, 1.0, int(g["seed"]), net=net)
+    assert np.array_equal(r["visits"][0], g["visits"][0])
+    assert r["moves"][0] == g["moves"][0]

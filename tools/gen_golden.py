@@ -392,6 +392,23 @@ def gen_rng():
     print("g5_rng written")
 
 
+# ---------------------------------------------------------------- G7 net-driven 8x8 game
+def gen_net_game8():
+    """One game at the benchmark's per-game settings (8x8, 5 in a row, 400 playouts, c_puct 5,
+    temp 1) played by the reference with its numpy net on seeded random weights."""
+    n = 8
+    net = ref_np_net.PolicyValueNetNumpy(n, n, helpers.torch_to_theano_layout(helpers.make_params(n, seed=108)))
+
+    def cb_net(board):
+        ap, v = net.policy_value_fn(board)
+        return [(a, float(np.float32(p))) for a, p in ap], float(np.float32(v))
+    g = record_game(n, 5, cb_net, 5, 400, 1.0, 3)
+    g["cb"] = "numpy_net_f32"
+    g["param_seed"] = 108
+    np.savez_compressed(os.path.join(OUT, "g7_net8.npz"), games=np.array([g], dtype=object))
+    print("g7_net8: %d plies winner %d" % (len(g["moves"]), g["winner"]))
+
+
 # ---------------------------------------------------------------- G6 augmentation
 def gen_equi():
     """train.py cannot be imported (Keras import at module level), so nothing here is a run of
@@ -447,6 +464,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "equi":
         gen_equi()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "net8":
+        gen_net_game8()
+        sys.exit(0)
     check_kats()
     check_spy_equivalence()
     gen_rules()
@@ -455,4 +475,5 @@ if __name__ == "__main__":
     gen_cnn()
     gen_games(helpers.make_params(6, seed=106))
     gen_equi()
+    gen_net_game8()
     print("done ->", OUT)
