@@ -428,8 +428,8 @@ def test_net_driven_games_do_not_depend_on_refill_mode_or_batch_width(az):
 @pytest.mark.parametrize("cnn_mode", [0, 1], ids=["f16x3", "f32"])
 def test_reference_c1_game_with_the_cnn(az, cnn_mode):
     """Configuration C1 end to end, and one game at C2's per-game settings: the reference's own
-    6x6 / 4-in-row / 200-playout and 8x8 / 5-in-row / 400-playout self-play games driven by its
-    numpy policy-value net (recorded by tools/gen_golden.py) are reproduced move for move and
+    6x6 / 4-in-row / 200-playout, 8x8 / 5-in-row / 400-playout and 15x15 / 5-in-row / 100-playout
+    self-play games driven by its numpy policy-value net (recorded by tools/gen_golden.py) are reproduced move for move and
     visit count for visit count with the leaf evaluations coming from the HIP CNN (the priors
     agree to ~1e-8, which never flips a PUCT decision in these games)."""
     games = [(g, 106) for g in load("g3_games.npz")["games"] if g["cb"] not in MODES]

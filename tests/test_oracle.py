@@ -169,7 +169,7 @@ def test_config2_game_with_net(oracle):
     """8x8, 5 in a row, 400 playouts (the benchmark's per-game settings), net-driven game recorded
     from the reference: the oracle's first search from the empty board must give the reference's
     visit counts; later plies may part ways (summation order of the two CPU nets differs)."""
-    g = load("g7_net8.npz")["games"][0]
+    g = [x for x in load("g7_net8.npz")["games"] if int(x["n"]) == 8][0]
     net = oracle.OracleNet(8, 8, helpers.make_params(8, seed=int(g["param_seed"])), precise=True)
     r = oracle.self_play(8, 5, "net", 5, 400, 1.0, int(g["seed"]), net=net)
     assert np.array_equal(r["visits"][0], g["visits"][0])

@@ -405,8 +405,21 @@ def gen_net_game8():
     g = record_game(n, 5, cb_net, 5, 400, 1.0, 3)
     g["cb"] = "numpy_net_f32"
     g["param_seed"] = 108
-    np.savez_compressed(os.path.join(OUT, "g7_net8.npz"), games=np.array([g], dtype=object))
-    print("g7_net8: %d plies winner %d" % (len(g["moves"]), g["winner"]))
+    games = [g]
+    print("g7_net8: 8x8 %d plies winner %d" % (len(g["moves"]), g["winner"]))
+    # a 15x15 game (wide action space, 4 bit-set words per colour), 100 playouts to keep it short
+    n = 15
+    net15 = ref_np_net.PolicyValueNetNumpy(n, n, helpers.torch_to_theano_layout(helpers.make_params(n, seed=115)))
+
+    def cb_net15(board):
+        ap, v = net15.policy_value_fn(board)
+        return [(a, float(np.float32(p))) for a, p in ap], float(np.float32(v))
+    g = record_game(n, 5, cb_net15, 5, 100, 1.0, 5)
+    g["cb"] = "numpy_net_f32"
+    g["param_seed"] = 115
+    games.append(g)
+    print("g7_net8: 15x15 %d plies winner %d" % (len(g["moves"]), g["winner"]))
+    np.savez_compressed(os.path.join(OUT, "g7_net8.npz"), games=np.array(games, dtype=object))
 
 
 # ---------------------------------------------------------------- G6 augmentation
