@@ -16,7 +16,7 @@
 // lanes of a ds_read_b128 group spread over the banks.  There is no halo: every image
 // ends with one all-zero row, and a tap that falls off the board reads that row
 // instead (one address select per position tile and tap).  This keeps the 8x8
-// footprint at ~70 KB so that two workgroups share a CU and one's tree / FC / softmax
+// footprint at ~72 KB so that two workgroups share a CU and one's tree / FC / softmax
 // phases overlap the other's MFMA phases.
 #pragma once
 #include "azg_cnn.hpp"
@@ -160,8 +160,7 @@ __device__ inline void conv3x3_f16(const half8 *wp, WRing<RING> &ring, const cha
     half8 (&ah)[RING] = ring.ah, (&al)[RING] = ring.al;
     // dense phase: take issue priority over the co-resident workgroup's scalar / f64 tree code
     if (COUT >= 64) __builtin_amdgcn_s_setprio(2);
-    // BPF (activation prefetch) costs 8*PT registers; the two-workgroups-per-CU builds drop it
-    // and let the other workgroup's waves cover the LDS latency instead.
+    // BPF (activation prefetch one k-step ahead) costs 8*PT registers for the second buffer set
     constexpr int NB = BPF ? 2 : 1;
     half8 bh[NB][PT], bl[NB][PT];
     if (BPF) {
