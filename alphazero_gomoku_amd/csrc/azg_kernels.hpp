@@ -247,21 +247,47 @@ __device__ inline void wave_reroot(const DevState &st, int g, int c, int lane)
         const int e = scan + lane;
         int oc = -1, k = 0;
         if (e < chunk_end) { oc = n.child[e]; k = meta_k(n.meta[e]); }
-        u64 m = __ballot(oc >= 0);
-        while (m) {
-            const int l = __ffsll((long long)m) - 1;
-            m &= m - 1;
-            const int ob = __shfl(oc, l), kk = __shfl(k, l);
-            for (int i = lane; i < kk; i += WAVE) {
-                n.P[freep + i] = o.P[ob + i];
-                n.N[freep + i] = o.N[ob + i];
-                n.Q[freep + i] = o.Q[ob + i];
-                n.child[freep + i] = o.child[ob + i];
-                n.meta[freep + i] = o.meta[ob + i];
-            }
-            if (lane == 0) n.child[scan + l] = freep;
-            freep += kk;
+        const int kk_l = oc >= 0 ? k : 0;
+        // destination of every queued node's child block: exclusive prefix sum of the block sizes
+        int incl = kk_l;
+#pragma unroll
+        for (int off = 1; off < WAVE; off <<= 1) {
+            const int v = __shfl_up(incl, off);
+            if (lane >= off) incl += v;
         }
+        const int dst_l = freep + incl - kk_l;
+        const int total = __shfl(incl, WAVE - 1);
+        if (oc >= 0) n.child[e] = dst_l;
+        // copy four child blocks per round: their loads are all in flight before the first store,
+        // so a round costs one memory round trip instead of four
+        const u64 have = __ballot(oc >= 0);
+        for (int g0 = 0; g0 < WAVE; g0 += 4) {
+            if (!((have >> g0) & 0xFULL)) continue;
+            float p4[4]; int n4[4], c4[4]; double q4[4]; unsigned m4[4]; int d4[4]; bool on4[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int ob = __shfl(oc, g0 + u), kk = __shfl(kk_l, g0 + u);
+                d4[u] = __shfl(dst_l, g0 + u);
+                on4[u] = ob >= 0 && lane < kk;          // blocks hold at most 64 children per pass
+                if (on4[u]) {
+                    p4[u] = o.P[ob + lane]; n4[u] = o.N[ob + lane]; q4[u] = o.Q[ob + lane];
+                    c4[u] = o.child[ob + lane]; m4[u] = o.meta[ob + lane];
+                }
+                // blocks wider than a wave (boards above 8x8): the remaining children
+                if (ob >= 0)
+                    for (int i = lane + WAVE; i < kk; i += WAVE) {
+                        n.P[d4[u] + i] = o.P[ob + i]; n.N[d4[u] + i] = o.N[ob + i]; n.Q[d4[u] + i] = o.Q[ob + i];
+                        n.child[d4[u] + i] = o.child[ob + i]; n.meta[d4[u] + i] = o.meta[ob + i];
+                    }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+                if (on4[u]) {
+                    n.P[d4[u] + lane] = p4[u]; n.N[d4[u] + lane] = n4[u]; n.Q[d4[u] + lane] = q4[u];
+                    n.child[d4[u] + lane] = c4[u]; n.meta[d4[u] + lane] = m4[u];
+                }
+        }
+        freep += total;
         wg_fence();
         scan = chunk_end;
     }
