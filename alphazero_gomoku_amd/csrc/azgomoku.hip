@@ -48,7 +48,7 @@ struct azg_handle {
         double temp = 1.0;
         uint32_t seed0 = 0;
         long long first = 0, stride = 1, total = -1;
-        hipEvent_t ev_mirror = nullptr;
+        hipEvent_t ev_mirror = nullptr, ev_noise = nullptr;
         hipStream_t copy_stream = nullptr;
         int par = 0;                             // parity of the sample set being produced
         int pend_n = 0, pend_games = 0;          // enqueued in the last step, complete by the next one
@@ -244,6 +244,7 @@ extern "C" void azg_destroy(azg_handle *h)
     if (h->sp.h_map) (void)hipHostFree(h->sp.h_map);
     if (h->sp.h_ids) (void)hipHostFree(h->sp.h_ids);
     if (h->sp.ev_mirror) (void)hipEventDestroy(h->sp.ev_mirror);
+    if (h->sp.ev_noise) (void)hipEventDestroy(h->sp.ev_noise);
     if (h->sp.copy_stream) (void)hipStreamDestroy(h->sp.copy_stream);
     for (auto &e : h->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -866,6 +867,7 @@ extern "C" int azg_selfplay_begin(azg_handle *h, double temp, uint32_t seed0, in
     const int B = h->cfg.n_games, S = h->st.S;
     auto &sp = h->sp;
     if (!sp.ev_mirror) HIPCHK(h, hipEventCreateWithFlags(&sp.ev_mirror, hipEventDisableTiming));
+    if (!sp.ev_noise) HIPCHK(h, hipEventCreateWithFlags(&sp.ev_noise, hipEventDisableTiming));
     if (!sp.copy_stream) HIPCHK(h, hipStreamCreateWithFlags(&sp.copy_stream, hipStreamNonBlocking));
     if (!sp.h_map) HIPCHK(h, hipHostMalloc((void **)&sp.h_map, (size_t)2 * 3 * B * S * sizeof(int)));
     if (!sp.h_ids) HIPCHK(h, hipHostMalloc((void **)&sp.h_ids, (size_t)2 * B * S * sizeof(long long)));
@@ -946,8 +948,12 @@ extern "C" int azg_selfplay_step(azg_handle *h, int *games_finished, int *sample
     auto &sp = h->sp;
     const int B = h->cfg.n_games, S = h->st.S;
     make_noise(h);                                  // while the search enqueued last time runs
-    HIPCHK(h, hipMemcpyAsync(h->d_noise, h->h_noise, (size_t)B * S * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipMemcpyAsync(h->d_u, h->h_u, (size_t)B * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    // the upload goes over the copy stream, i.e. also while that search runs (the previous
+    // advance, the last reader of these buffers, completed before the last step returned)
+    HIPCHK(h, hipMemcpyAsync(h->d_noise, h->h_noise, (size_t)B * S * sizeof(double), hipMemcpyHostToDevice, sp.copy_stream));
+    HIPCHK(h, hipMemcpyAsync(h->d_u, h->h_u, (size_t)B * sizeof(double), hipMemcpyHostToDevice, sp.copy_stream));
+    HIPCHK(h, hipEventRecord(sp.ev_noise, sp.copy_stream));
+    HIPCHK(h, hipStreamWaitEvent(h->stream, sp.ev_noise, 0));
     hipLaunchKernelGGL(advance_kernel, dim3((B + 3) / 4), dim3(256), 0, h->stream, h->st, sp.temp, h->d_noise, h->d_u,
                        (const int *)nullptr, ADV_SAMPLE | ADV_RECORD | ADV_BOARD | ADV_REROOT | ADV_RESTART,
                        (int *)nullptr, (double *)nullptr, (long long)sp.first, (long long)sp.stride, (long long)sp.total);
