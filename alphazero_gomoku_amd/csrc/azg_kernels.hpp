@@ -347,10 +347,14 @@ __global__ __launch_bounds__(256) void advance_kernel(DevState st, double temp, 
         if (flags & ADV_SAMPLE) {
             // np.random.choice(acts, p = 0.75*probs + 0.25*dirichlet): cdf = cumsum(p);
             // cdf /= cdf[-1]; index = searchsorted(cdf, u, side='right')
+            // p = 0.75*probs + 0.25*noise element-wise (all lanes, coalesced noise read), then the
+            // sequential cumsum of np.cumsum on one lane
+            for (int i = lane; i < K; i += WAVE) cdf[i] = 0.75 * e[i] + 0.25 * noise[(size_t)g * S + i];
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
             if (lane == 0) {
                 double run = 0.0;
                 for (int i = 0; i < K; i++) {
-                    run += 0.75 * e[i] + 0.25 * noise[(size_t)g * S + i];
+                    run += cdf[i];
                     cdf[i] = run;
                 }
             }
