@@ -49,11 +49,12 @@ __global__ __launch_bounds__(256, (F16 && MODE == 0 && N <= 8) ? 2 : 1) void sea
 {
     using G = typename GeomPick<(MODE == 0 ? N : 4), (MODE == 0 ? T : 1), F16>::type;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    GameLds *gls = reinterpret_cast<GameLds *>(smem + (MODE == 0 ? G::END : 0));
+    using GL = GameLdsT<(MODE == 0 ? N * N + 1 : MAXS + 1)>;
+    GL *gls = reinterpret_cast<GL *>(smem + (MODE == 0 ? G::END : 0));
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const bool tree_wave = wave < T;
     const int g = blockIdx.x * T + wave;
-    GameLds *gl = &gls[tree_wave ? wave : 0];
+    GL *gl = &gls[tree_wave ? wave : 0];
 
     if (tree_wave) {
         const bool live = (g < st.B) && st.status[g] == 0;
@@ -110,7 +111,7 @@ __global__ __launch_bounds__(256, (F16 && MODE == 0 && N <= 8) ? 2 : 1) void sea
             for (int t = 0; t < T; t++) any |= gls[t].live && gls[t].need_eval;
             if (any) {
                 net_forward<G, F16>(st.net, smem, [&](int leaf, int row, int col, float *out) {
-                    const GameLds *q = &gls[leaf];
+                    const GL *q = &gls[leaf];
                     planes_at(q->leaf_bb, N, q->leaf_ply, q->leaf_last, q->first_player, q->live != 0, row, col, out);
                 }, prof, gate);
             } else {

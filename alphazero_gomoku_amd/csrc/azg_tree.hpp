@@ -24,13 +24,16 @@ __device__ inline u64 mix64(u64 z)
 // bit c of a MAXW-word set kept in LDS or global memory
 __device__ inline bool bb_has(const u64 *set, int c) { return (set[c >> 6] >> (c & 63)) & 1ULL; }
 
-// Working copy of one game during a search (lives in LDS).
-struct GameLds {
+// Working copy of one game during a search (lives in LDS).  PL = longest possible path (root ..
+// leaf): cells + 1; the CNN kernels instantiate it for their board so that two workgroups fit
+// on a CU.
+template <int PL>
+struct GameLdsT {
     u64 root_bb[2][MAXW];
     u64 leaf_bb[2][MAXW];
-    double path_q[MAXS + 1];   // Q of the path's edges as read during the descent
-    int path[MAXS + 1];        // edge indices root .. leaf
-    int path_n[MAXS + 1];      // visit counts of the path's edges as read during the descent
+    double path_q[PL];   // Q of the path's edges as read during the descent
+    int path[PL];        // edge indices root .. leaf
+    int path_n[PL];      // visit counts of the path's edges as read during the descent
     int used;                  // edges in use in the live arena (DevState::used during a launch)
     int root_act;              // action stored in the root edge
     int depth;                 // entries in path
@@ -43,6 +46,7 @@ struct GameLds {
     int need_eval;             // leaf needs priors/value from the provider
     int gid;                   // slot index
 };
+typedef GameLdsT<MAXS + 1> GameLds;
 
 struct TreeView {              // live arena of one game
     float *P; int *N; double *Q; int *child; unsigned *meta;
@@ -200,7 +204,8 @@ __device__ inline int game_end_1w(u64 s1, u64 s2, int N, int S, int nrow, int ns
 // Descend from the root to a leaf (mcts_alphaZero.py:122-129).  Lanes hold one child
 // each (four at most on 16x16); the argmax keeps the first maximum in ascending child
 // order, which is the order `max()` meets them in the reference.
-__device__ inline Descent wave_select(const DevState &st, const TreeView &t, GameLds *gl, int lane)
+template <class GL>
+__device__ inline Descent wave_select(const DevState &st, const TreeView &t, GL *gl, int lane)
 {
     // leaf board starts as a copy of the root board (copy.deepcopy, :162)
     if (lane < 2 * MAXW) ((u64 *)gl->leaf_bb)[lane] = ((u64 *)gl->root_bb)[lane];
@@ -265,8 +270,8 @@ __device__ inline Descent wave_select(const DevState &st, const TreeView &t, Gam
 // TreeNode.expand (:38-45): one child per empty cell in ascending order, prior taken
 // from the provider's per-cell output without renormalisation.  `prior_of(cell)`
 // returns the float32 prior.  Returns false when the arena is full.
-template <typename PriorFn>
-__device__ inline bool wave_expand(const DevState &st, const TreeView &t, GameLds *gl,
+template <class GL, typename PriorFn>
+__device__ inline bool wave_expand(const DevState &st, const TreeView &t, GL *gl,
                                    const Descent &d, int g, int lane, PriorFn prior_of)
 {
     const int leaf = d.leaf;
@@ -305,7 +310,8 @@ __device__ inline bool wave_expand(const DevState &st, const TreeView &t, GameLd
 // ---------------------------------------------------------------- backup
 // update_recursive(-leaf_value) (:57-73): N += 1; Q += 1.0*(x - Q)/N from the leaf up
 // to and including the root, x changing sign at every step.
-__device__ inline void wave_backup(const TreeView &t, const GameLds *gl, int depth, double leaf_value,
+template <class GL>
+__device__ inline void wave_backup(const TreeView &t, const GL *gl, int depth, double leaf_value,
                                    int lane)
 {
     const int d = depth;

@@ -123,7 +123,7 @@ template <int N, int T, bool F16>
 static SearchLaunch net_launch()
 {
     using G = typename GeomPick<N, T, F16>::type;
-    return {search_kernel<N, T, 0, F16>, T, (size_t)G::END * 4 + T * sizeof(GameLds)};
+    return {search_kernel<N, T, 0, F16>, T, (size_t)G::END * 4 + T * sizeof(GameLdsT<N * N + 1>)};
 }
 
 static bool pick_search(int N, int mode, int cnn_mode, SearchLaunch *out)
