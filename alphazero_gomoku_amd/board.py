@@ -16,6 +16,28 @@ class Board(object):
         self.players = [1, 2]
         self.states = {}
         self._stones = [0, 0]
+        self.move_target = []
+
+    # game.py:25-58
+    def move_in_rect(self, move, rect):
+        row, col = move // self.width, move % self.width
+        return rect[1] <= row <= rect[0] and rect[2] <= col <= rect[3]
+
+    def get_move_target(self):
+        """The cells the rollout opponent considers: empty cells inside the stones' bounding box
+        grown by two (rows and columns 5..9 on an empty board)."""
+        if not self.states:
+            top, bottom, left, right = 9, 5, 5, 9
+        else:
+            rows = [m // self.width for m in self.states]
+            cols = [m % self.width for m in self.states]
+            top, bottom, left, right = max(rows), min(rows), min(cols), max(cols)
+            step = 2
+            top = top + step if top <= self.height - step else self.height
+            bottom = bottom - step if bottom >= step else 0
+            left = left - step if left >= step else 0
+            right = right + step if right <= self.width - step else self.width
+        self.move_target = [x for x in self.availables if self.move_in_rect(x, [top, bottom, left, right])]
 
     # game.py:60-68
     def init_board(self, start_player=0):

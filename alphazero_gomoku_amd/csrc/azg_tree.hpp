@@ -203,8 +203,10 @@ __device__ inline int game_end_1w(u64 s1, u64 s2, int N, int S, int nrow, int ns
 // ---------------------------------------------------------------- select
 // Descend from the root to a leaf (mcts_alphaZero.py:122-129).  Lanes hold one child
 // each (four at most on 16x16); the argmax keeps the first maximum in ascending child
-// order, which is the order `max()` meets them in the reference.
-template <class GL>
+// order, which is the order `max()` meets them in the reference.  UNIFORM_P: every child of a
+// node carries the prior 1/K in double (the rollout opponent's policy_value_fn,
+// mcts_pure.py:33-46), computed instead of loaded.
+template <class GL, bool UNIFORM_P = false>
 __device__ inline Descent wave_select(const DevState &st, const TreeView &t, GL *gl, int lane)
 {
     // leaf board starts as a copy of the root board (copy.deepcopy, :162)
@@ -226,12 +228,12 @@ __device__ inline Descent wave_select(const DevState &st, const TreeView &t, GL 
         for (int i = lane; i < K; i += WAVE) {
             const int ei = child + i;
             const double q = t.Q[ei];
-            const float p = t.P[ei];
+            const double p = UNIFORM_P ? 1.0 / (double)K : (double)t.P[ei];
             const int n = t.N[ei];
             const int ch = t.child[ei];
             const unsigned mt = t.meta[ei];
             // get_value (:82-83): c_puct * P * sqrt(Np) / (1 + n), left to right, then Q + u
-            const double u = ((st.c_puct * (double)p) * sq) / (double)(1 + n);
+            const double u = ((st.c_puct * p) * sq) / (double)(1 + n);
             const double s = q + u;
             if (s > best) { best = s; bq = q; bidx = i; bchild = ch; bn = n; bmeta = mt; }
         }

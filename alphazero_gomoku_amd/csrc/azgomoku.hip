@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "azg_kernels.hpp"
+#include "azg_pure.hpp"
 #include "np_legacy_rng.hpp"
 
 using namespace azg;
@@ -774,6 +775,38 @@ extern "C" int azg_drain_samples(azg_handle *h, int max_samples, float *states, 
     if (game_id) HIPCHK(h, hipMemcpyAsync(game_id, di, (size_t)n * sizeof(long long), hipMemcpyDefault, h->stream));
     if (ply) HIPCHK(h, hipMemcpyAsync(ply, dl, (size_t)n * sizeof(int), hipMemcpyDefault, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    return AZG_OK;
+}
+
+// ---------------------------------------------------------------- rollout opponent
+extern "C" int azg_pure_search(azg_handle *h, int n_playout, uint32_t *mt_state, int32_t *moves_out)
+{
+    if (!h || !mt_state || !moves_out) return fail(h, AZG_EINVAL, "null argument");
+    NOT_WHILE_PIPELINED(h);
+    if (n_playout < 1) return fail(h, AZG_EINVAL, "n_playout must be positive");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    const int B = h->cfg.n_games, S = h->st.S;
+    // every playout expands at most one node of at most S children
+    if ((long long)n_playout * S + 1 > (long long)h->st.cap)
+        return fail(h, AZG_EARENA, "%d rollout playouts need arena_nodes >= %d (have %d)", n_playout, n_playout, h->cfg.arena_nodes);
+    for (int g = 0; g < B; g++)
+        if (mt_state[(size_t)g * 625 + 624] > 624u) return fail(h, AZG_EINVAL, "slot %d: generator position %u out of range", g, mt_state[(size_t)g * 625 + 624]);
+    void *d_mt, *d_mv;
+    int rc;
+    if ((rc = scratch_get(h, 8, (size_t)B * 625 * sizeof(uint32_t), &d_mt))) return rc;
+    if ((rc = scratch_get(h, 9, (size_t)B * sizeof(int), &d_mv))) return rc;
+    HIPCHK(h, hipMemcpyAsync(d_mt, mt_state, (size_t)B * 625 * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
+    if (S <= 64)
+        hipLaunchKernelGGL(pure_search_kernel<1>, dim3((B + 3) / 4), dim3(256), 0, h->stream, h->st, n_playout, (unsigned *)d_mt, (int *)d_mv);
+    else
+        hipLaunchKernelGGL(pure_search_kernel<4>, dim3((B + 3) / 4), dim3(256), 0, h->stream, h->st, n_playout, (unsigned *)d_mt, (int *)d_mv);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipMemcpyAsync(mt_state, d_mt, (size_t)B * 625 * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(moves_out, d_mv, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    rc = refresh_mirrors(h);                                  // synchronises the stream; picks up the arena-overflow flag
+    if (rc != AZG_OK) return rc;
+    for (int g = 0; g < B; g++)
+        if (h->h_err[g] & 1) return fail(h, AZG_EARENA, "slot %d: the tree outgrew its arena", g);
     return AZG_OK;
 }
 

@@ -87,6 +87,16 @@ class SelfPlayEngine:
     def search(self):
         self._chk(self.L.azg_search(self.h))
 
+    def pure_search(self, n_playout, mt_state):
+        """The rollout opponent's move for every live slot (mcts_pure.py:214-231, 261-268).
+        mt_state: uint32 [B, 625], per slot the 624 MT19937 key words and the position of
+        np.random.get_state(); updated in place.  Returns the moves (int32 [B], -1 = not live)."""
+        assert mt_state.dtype == np.uint32 and mt_state.shape == (self.B, 625) and mt_state.flags.c_contiguous
+        moves = np.zeros(self.B, dtype=np.int32)
+        self._chk(self.L.azg_pure_search(self.h, int(n_playout), mt_state.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                         moves.ctypes.data_as(C.POINTER(C.c_int32))))
+        return moves
+
     def root_stats(self):
         visits = np.zeros((self.B, self.S), dtype=np.int32)
         q = np.zeros((self.B, self.S))

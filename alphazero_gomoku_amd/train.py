@@ -6,7 +6,8 @@ What is kept: the constructor's hyper-parameters and their meaning, collect_self
 buffer, `epochs` train steps with the KL early stop, the adaptive learning-rate multiplier and the
 explained-variance report) and run().  What differs: games are played `play_batch_size` at a time
 on the GPU instead of one by one; hyper-parameters come as keyword arguments instead of the YAML
-file; the evaluation against the pure-MCTS player (train.py:216-276) is not part of this class.
+file; policy_evaluate plays the rollout opponent only (the external Yixin engine of
+train.py:231-245 is not supported).
 With torch.distributed initialised every rank plays its share of the games, all ranks gather all
 tuples, and a policy update is one data-parallel step (each rank its slice of the mini-batch)."""
 import random
@@ -23,7 +24,7 @@ class TrainPipeline:
     def __init__(self, board_width=8, board_height=8, n_in_row=5, init_model=None, learn_rate=2e-3,
                  lr_multiplier=1.0, temp=1.0, n_playout=400, c_puct=5, buffer_size=10000, batch_size=512,
                  play_batch_size=1, epochs=5, kl_targ=0.02, check_freq=50, game_batch_num=1500,
-                 n_parallel=1024, device=0, seed0=0, policy_value_net=None):
+                 n_parallel=1024, device=0, seed0=0, policy_value_net=None, pure_mcts_playout_num=1000):
         from .net import PolicyValueNet
         self.board_width, self.board_height, self.n_in_row = board_width, board_height, n_in_row
         self.board = Board(width=board_width, height=board_height, n_in_row=n_in_row)
@@ -34,6 +35,8 @@ class TrainPipeline:
         self.data_buffer = ReplayBuffer(buffer_size, board_width)            # deque(maxlen) of train.py:82
         self.play_batch_size, self.epochs, self.kl_targ = play_batch_size, epochs, kl_targ
         self.check_freq, self.game_batch_num = check_freq, game_batch_num
+        self.best_win_ratio = 0.2                                            # train.py:88
+        self.pure_mcts_playout_num = pure_mcts_playout_num
         self.policy_value_net = policy_value_net or PolicyValueNet(board_width, board_height, model_file=init_model,
                                                                    device=device)
         self.device, self.seed0, self.games_played = device, seed0, 0
@@ -101,8 +104,29 @@ class TrainPipeline:
         self.last_kl = kl
         return loss, entropy
 
-    # ---- train.py:278-330 (self-play -> update; evaluation left out) ----------------------------
-    def run(self, on_batch=None):
+    # ---- train.py:216-276 --------------------------------------------------------------------
+    def policy_evaluate(self, n_games=10):
+        """Play the current policy (evaluation mode: no exploration noise, fresh tree per move)
+        against the rollout MCTS player, sides alternating, and return the win ratio
+        (wins + half the ties) / n_games.  Only for monitoring the progress of training."""
+        from collections import defaultdict
+        from .mcts import MCTSPlayer
+        from .mcts_pure import MCTSPlayer as MCTS_Pure
+        current_mcts_player = MCTSPlayer(self.policy_value_net.policy_value_fn, c_puct=self.c_puct,
+                                         n_playout=self.n_playout, device=self.device)
+        pure_mcts_player = MCTS_Pure(c_puct=5, n_playout=self.pure_mcts_playout_num, device=self.device)
+        win_cnt = defaultdict(int)
+        for i in range(n_games):
+            winner = self.game.start_play(current_mcts_player, pure_mcts_player, start_player=i % 2, is_shown=0)
+            win_cnt[winner] += 1
+        self.last_win_cnt = dict(win_cnt)
+        return 1.0 * (win_cnt[1] + 0.5 * win_cnt[-1]) / n_games
+
+    # ---- train.py:278-340 --------------------------------------------------------------------
+    def run(self, on_batch=None, best_model=None, evaluate_games=10):
+        """Self-play -> policy update, and every check_freq batches an evaluation against the rollout
+        player: a new best win ratio saves the model to best_model (when given); a perfect score
+        strengthens the opponent by 1000 playouts and resets the mark (train.py:324-338)."""
         for i in range(self.game_batch_num):
             self.collect_selfplay_data(self.play_batch_size)
             loss = entropy = None
@@ -110,4 +134,13 @@ class TrainPipeline:
                 loss, entropy = self.policy_update()
             if on_batch is not None:
                 on_batch(i, self.episode_len, loss, entropy)
+            if self.check_freq and (i + 1) % self.check_freq == 0 and self.rank == 0 and evaluate_games > 0:
+                win_ratio = self.policy_evaluate(evaluate_games)
+                if win_ratio > self.best_win_ratio:
+                    self.best_win_ratio = win_ratio
+                    if best_model:
+                        self.policy_value_net.save_model(best_model)
+                    if self.best_win_ratio == 1.0 and self.pure_mcts_playout_num < 5000:
+                        self.pure_mcts_playout_num += 1000
+                        self.best_win_ratio = 0.0
         return self.policy_value_net

@@ -157,6 +157,20 @@ int azg_selfplay_fetch(azg_handle *h, float *states, double *pi, float *z,
                        int64_t *game_id, int32_t *ply);
 int azg_selfplay_end(azg_handle *h, int *samples_ready);
 
+/* The evaluation opponent of train.py:249,264: mcts_pure.MCTSPlayer.get_action
+ * (mcts_pure.py:261-268) for every live slot, i.e. MCTS.get_move (mcts_pure.py:214-231) from a
+ * fresh root: n_playout playouts, each expanding the leaf over Board.get_move_target's cells
+ * (game.py:35-58) with prior 1/K and finishing the game by random moves (_evaluate_rollout,
+ * mcts_pure.py:193-212), then the first most-visited root child.  The rollouts draw
+ * np.random.rand(len(move_target)) per step from the slot's numpy-legacy MT19937 stream:
+ * mt_state [B][625] (host) holds, per slot, the 624 key words and the position as
+ * np.random.get_state() returns them, and is updated in place, so that
+ * np.random.set_state() continues the stream where the reference would be.  moves_out [B]
+ * (host): the chosen cell, -1 for slots that are not live.  The board is not changed; the
+ * tree stays in the slot (azg_root_stats shows the visit counts) until the next search or
+ * azg_update_with_move.  Needs arena_nodes >= n_playout (AZG_EARENA otherwise). */
+int azg_pure_search(azg_handle *h, int n_playout, uint32_t *mt_state, int32_t *moves_out);
+
 /* PolicyValueNet.policy_value (policy_value_net_pytorch.py:80-94): states f32
  * [n,4,N,N] -> probs f32 [n,S] (exp of the log-softmax), values f32 [n].  Host or
  * device pointers. */

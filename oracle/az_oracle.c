@@ -580,6 +580,131 @@ void azo_mcts_update_with_move(azo_mcts *m, int last_move)
 }
 
 /* ======================================================================= */
+/* Pure (rollout) MCTS opponent -- mcts_pure.py, with the move filter of     */
+/* game.py:25-58 (Board.get_move_target)                                     */
+/* ======================================================================= */
+
+/* game.py:35-58 get_move_target: the empty cells inside the bounding box of all
+ * stones grown by 2 (clipped exactly as the reference clips it; an empty board
+ * uses rows/columns 5..9).  Ascending order, like availables.  Returns the count. */
+int azo_board_move_target(const azo_board *b, int *out)
+{
+    const int W = b->width, H = b->height;
+    int top, bottom, left, right;
+    if (b->n_stones == 0) {
+        top = 9; bottom = 5; left = 5; right = 9;               /* game.py:40-41 */
+    } else {
+        top = -1; bottom = 1 << 30; left = 1 << 30; right = -1;
+        for (int m = 0; m < W * H; m++) {
+            if (!b->cell[m]) continue;
+            int r = m / W, c = m % W;
+            if (r > top) top = r;
+            if (r < bottom) bottom = r;
+            if (c < left) left = c;
+            if (c > right) right = c;
+        }
+        const int step = 2;                                     /* game.py:48-52 */
+        top = top <= H - step ? top + step : H;
+        bottom = bottom >= step ? bottom - step : 0;
+        left = left >= step ? left - step : 0;
+        right = right <= W - step ? right + step : W;
+    }
+    int k = 0;
+    for (int i = 0; i < b->n_avail; i++) {                      /* game.py:25-33,56 */
+        int m = b->avail[i], row = m / W, col = m % W;
+        if (row >= bottom && row <= top && col >= left && col <= right) out[k++] = m;
+    }
+    return k;
+}
+
+/* mcts_pure.py:193-212 _evaluate_rollout with rollout_policy_fn (:15-30): every step draws
+ * np.random.rand(len(move_target)) and plays the first maximum. */
+static double pure_rollout(azo_board *b, azo_rng *rng)
+{
+    const int player = b->current_player;
+    int end = 0, winner = -1;
+    for (int i = 0; i < 1000; i++) {
+        azo_board_game_end(b, &end, &winner);
+        if (end) break;
+        int tgt[AZO_MAX_CELLS];
+        const int k = azo_board_move_target(b, tgt);
+        int best = -1; double best_v = 0.0;
+        for (int j = 0; j < k; j++) {
+            double v = azo_rng_double(rng);
+            if (best < 0 || v > best_v) { best = tgt[j]; best_v = v; }
+        }
+        azo_board_do_move(b, best);
+    }
+    if (winner == -1) return 0.0;
+    return winner == player ? 1.0 : -1.0;
+}
+
+/* mcts_pure.py:156-191 _playout: descend, expand over move_target with P = 1/K (float64,
+ * policy_value_fn :33-46), rollout, update_recursive(-leaf_value). */
+static void pure_playout(azo_mcts *m, azo_board *state, azo_rng *rng)
+{
+    int nd = m->root;
+    while (m->nodes[nd].first_child >= 0) {
+        const node *par = &m->nodes[nd];
+        const double sq = sqrt((double)par->n_visits);
+        int best = -1; double best_v = 0.0;
+        for (int i = 0; i < par->n_children; i++) {
+            const node *ch = &m->nodes[par->first_child + i];
+            double u = ((m->c_puct * ch->P) * sq) / (double)(1 + ch->n_visits);
+            double v = ch->Q + u;
+            if (best < 0 || v > best_v) { best = i; best_v = v; }
+        }
+        nd = m->nodes[nd].first_child + best;
+        azo_board_do_move(state, m->nodes[nd].action);
+    }
+    int tgt[AZO_MAX_CELLS];
+    const int k = azo_board_move_target(state, tgt);            /* :176 via policy_value_fn */
+    int end, winner;
+    azo_board_game_end(state, &end, &winner);
+    if (!end && k > 0) {
+        long base = pool_alloc(m, k);
+        for (int i = 0; i < k; i++) node_init(&m->nodes[base + i], nd, tgt[i], 1.0 / (double)k);
+        m->nodes[nd].first_child = (int)base;
+        m->nodes[nd].n_children = k;
+    }
+    const double leaf_value = pure_rollout(state, rng);
+    double x = -leaf_value;
+    for (int cur = nd; cur >= 0; cur = m->nodes[cur].parent) {
+        node *p = &m->nodes[cur];
+        p->n_visits += 1;
+        p->Q += 1.0 * (x - p->Q) / (double)p->n_visits;
+        x = -x;
+    }
+}
+
+/* mcts_pure.py:214-231 get_move from a fresh root (MCTSPlayer.get_action resets the tree after
+ * every move, :261-268): n_playout playouts, then the first most-visited root child.  acts /
+ * visits / q describe the root's children; returns the move (-1 when the root has none). */
+int azo_pure_get_move(const azo_board *state, double c_puct, int n_playout, azo_rng *rng,
+                      int *n_children, int *acts, int *visits, double *q, int *root_visits)
+{
+    azo_mcts *m = azo_mcts_new(NULL, NULL, c_puct, n_playout);
+    for (int n = 0; n < n_playout; n++) {
+        azo_board copy = *state;
+        pure_playout(m, &copy, rng);
+    }
+    const node *root = &m->nodes[m->root];
+    const int k = root->first_child >= 0 ? root->n_children : 0;
+    int move = -1, best = -1;
+    for (int i = 0; i < k; i++) {
+        const node *ch = &m->nodes[root->first_child + i];
+        if (acts) acts[i] = ch->action;
+        if (visits) visits[i] = ch->n_visits;
+        if (q) q[i] = ch->Q;
+        if (ch->n_visits > best) { best = ch->n_visits; move = ch->action; }
+    }
+    if (n_children) *n_children = k;
+    if (root_visits) *root_visits = root->n_visits;
+    azo_mcts_free(m);
+    return move;
+}
+
+/* ======================================================================= */
 /* Self-play -- MCTSPlayer.get_action (mcts_alphaZero.py:212-260) inside     */
 /* Game.start_self_play (game.py:360-416)                                   */
 /* ======================================================================= */

@@ -84,6 +84,13 @@ int  azo_mcts_root_children(const azo_mcts *m, int *acts, int *visits, double *q
 int  azo_mcts_root_visits(const azo_mcts *m);
 long azo_mcts_node_count(const azo_mcts *m);
 
+/* ---- pure (rollout) MCTS opponent (mcts_pure.py, game.py:25-58) ---------- */
+int azo_board_move_target(const azo_board *b, int *out);
+/* One MCTSPlayer.get_action of mcts_pure.py from a fresh root; the rollouts draw from rng
+ * (the global numpy stream in the reference).  Returns the move. */
+int azo_pure_get_move(const azo_board *state, double c_puct, int n_playout, azo_rng *rng,
+                      int *n_children, int *acts, int *visits, double *q, int *root_visits);
+
 /* ---- self-play (MCTSPlayer.get_action + Game.start_self_play) ----------- */
 typedef struct azo_game_record {
     int n_plies;

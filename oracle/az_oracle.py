@@ -89,6 +89,10 @@ def lib():
                                      C.c_int, C.c_double, C.c_uint32, C.c_int, C.c_int,
                                      C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.azo_self_play_many.restype = C.c_long
+    L.azo_board_move_target.argtypes = [C.POINTER(Board), C.POINTER(C.c_int)]
+    L.azo_pure_get_move.argtypes = [C.POINTER(Board), C.c_double, C.c_int, C.c_void_p, C.POINTER(C.c_int),
+                                    C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double),
+                                    C.POINTER(C.c_int)]
     _lib = L
     return L
 
@@ -145,6 +149,12 @@ class OracleBoard:
 
     def state_key(self):
         return int(lib().azo_state_key(C.byref(self.b)))
+
+    def move_target(self):
+        """Board.get_move_target (game.py:35-58): the cells the rollout opponent considers."""
+        out = (C.c_int * MAX_CELLS)()
+        k = lib().azo_board_move_target(C.byref(self.b), out)
+        return [out[i] for i in range(k)]
 
 
 class OracleNet:
@@ -261,6 +271,16 @@ class OracleRng:
         self.buf = C.create_string_buffer(624 * 4 + 8)
         lib().azo_rng_seed(self.buf, int(seed))
 
+    def get_state(self):
+        """(key[624] uint32, pos) like np.random.get_state()[1:3]."""
+        raw = np.frombuffer(self.buf, dtype=np.uint32, count=625).copy()
+        return raw[:624], int(raw[624])
+
+    def set_state(self, key, pos):
+        raw = np.frombuffer(self.buf, dtype=np.uint32, count=625)
+        raw[:624] = np.asarray(key, dtype=np.uint32)
+        raw[624] = int(pos)
+
     def random_sample(self):
         return lib().azo_rng_double(self.buf)
 
@@ -268,6 +288,21 @@ class OracleRng:
         out = np.zeros(k)
         lib().azo_rng_dirichlet(self.buf, float(alpha), int(k), out.ctypes.data_as(C.POINTER(C.c_double)))
         return out
+
+
+def pure_get_move(board, c_puct, n_playout, rng):
+    """mcts_pure.MCTSPlayer.get_action from a fresh root on an OracleBoard; rng: OracleRng (the
+    global numpy stream of the reference).  Returns (move, visits by cell, root visits)."""
+    S = board.width * board.height
+    k, rv = C.c_int(), C.c_int()
+    acts, vis = (C.c_int * MAX_CELLS)(), (C.c_int * MAX_CELLS)()
+    q = (C.c_double * MAX_CELLS)()
+    move = lib().azo_pure_get_move(C.byref(board.b), float(c_puct), int(n_playout), rng.buf, C.byref(k), acts, vis, q,
+                                   C.byref(rv))
+    visits = np.zeros(S, dtype=np.int32)
+    for i in range(k.value):
+        visits[acts[i]] = vis[i]
+    return move, visits, rv.value
 
 
 def equi_data(play_data, board_height, board_width):

@@ -91,3 +91,11 @@ def random_positions(n, n_in_row, count, seed):
         length = int(rs.randint(0, max(1, n * n - n_in_row)))
         out.append([int(x) for x in rs.permutation(n * n)[:length]])
     return out
+
+
+def choice_index(probs, u):
+    """np.random.choice(acts, p=probs) for one draw, given its uniform u: cumulative sums,
+    normalised by the last one, searchsorted(side='right') (numpy/random/mtrand.pyx)."""
+    cdf = np.cumsum(np.asarray(probs, dtype=np.float64))
+    cdf /= cdf[-1]
+    return int(min(np.searchsorted(cdf, u, side="right"), len(cdf) - 1))

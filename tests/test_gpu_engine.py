@@ -454,3 +454,132 @@ def test_reference_c1_game_with_the_cnn(az, cnn_mode):
         assert np.array_equal(s["z"], g["z"].astype(np.float32))
         assert np.array_equal(s["states"], g["states"].astype(np.float32))
         eng.close()
+
+
+def _stream_words(seed):
+    st = np.random.RandomState(int(seed)).get_state()
+    w = np.empty((1, 625), dtype=np.uint32)
+    w[0, :624], w[0, 624] = st[1], st[2]
+    return w
+
+
+def _set_case_position(eng, slot, c):
+    first = int(c["start_player"]) + 1
+    pre = [int(m) for m in c["pre"]]
+    cur = first if len(pre) % 2 == 0 else 3 - first
+    eng.set_position(slot, stones_of(pre, first), pre[-1] if pre else -1, cur)
+
+
+def test_rollout_opponent_matches_reference(az):
+    """azg_pure_search against searches of the reference's mcts_pure.MCTSPlayer (fixture g8): the
+    move, every root visit count, the root's own count and the numpy stream handed back
+    (position, key words and the next double) are bit-exact, on 6x6, 8x8, 9x9 and 15x15."""
+    cases = load("g8_pure.npz")["cases"]
+    assert len(cases) >= 8
+    for c in cases:
+        n, k, npo = int(c["n"]), int(c["k"]), int(c["n_playout"])
+        eng = az.SelfPlayEngine(n, k, npo, 1, float(c["c_puct"]), prior_mode=az.PRIOR_UNIFORM32, arena_nodes=npo + 8)
+        eng.reset_games()
+        _set_case_position(eng, 0, c)
+        words = _stream_words(c["seed"])
+        moves = eng.pure_search(npo, words)
+        visits, _, prior, root_n = eng.root_stats()
+        assert moves[0] == c["move"] and root_n[0] == c["root_visits"], (n, int(c["seed"]))
+        assert np.array_equal(visits[0], c["visits"])
+        kk = int((c["visits"] > 0).sum())
+        assert kk == 0 or abs(prior[0].max() - 1.0 / max(1, (prior[0] > 0).sum())) < 1e-7
+        assert int(words[0, 624]) == c["rng_pos"] and int(np.bitwise_xor.reduce(words[0, :624])) == c["rng_key_crc"]
+        rs = np.random.RandomState(0)
+        rs.set_state(("MT19937", words[0, :624], int(words[0, 624]), 0, 0.0))
+        assert rs.random_sample() == c["next_double"]
+        eng.close()
+
+
+def test_rollout_opponent_slots_are_independent(az, oracle):
+    """Several slots searched in one launch (different positions, different streams, one of
+    them not live) give what the oracle gives for each slot alone."""
+    n, k, npo = 8, 5, 90
+    pres = [[], [27], [27, 28, 35, 36, 20], [0, 63, 7, 56, 9], [10, 11, 12, 13]]
+    B = len(pres) + 1
+    eng = az.SelfPlayEngine(n, k, npo, B, 5.0, prior_mode=az.PRIOR_UNIFORM32, arena_nodes=npo + 8)
+    eng.reset_games(mask=np.array([1] * len(pres) + [0], dtype=np.uint8))      # the last slot stays idle
+    words = np.zeros((B, 625), dtype=np.uint32)
+    for g, pre in enumerate(pres):
+        eng.set_position(g, stones_of(pre, 1), pre[-1] if pre else -1, 1 if len(pre) % 2 == 0 else 2)
+        words[g] = _stream_words(100 + g)[0]
+    words[B - 1] = _stream_words(999)[0]
+    idle_before = words[B - 1].copy()
+    moves = eng.pure_search(npo, words)
+    visits, _, _, root_n = eng.root_stats()
+    assert moves[B - 1] == -1
+    for g, pre in enumerate(pres):
+        b = oracle.OracleBoard(n, n, k)
+        b.init_board(0)
+        for m in pre:
+            b.do_move(m)
+        rng = oracle.OracleRng(100 + g)
+        mv, vis, rn = oracle.pure_get_move(b, 5.0, npo, rng)
+        key, pos = rng.get_state()
+        assert moves[g] == mv and root_n[g] == rn and np.array_equal(visits[g], vis), g
+        assert int(words[g, 624]) == pos and np.array_equal(words[g, :624], key), g
+    assert np.array_equal(words[B - 1], idle_before) or moves[B - 1] == -1
+    with pytest.raises(az._lib.AzgError) as e:
+        eng.pure_search(npo + 100, words)                    # one node per playout must fit the arena
+    assert e.value.code == -4
+    eng.close()
+
+
+class _Spy:
+    """Forwards to a player and logs its moves (Game.start_play keeps none)."""
+
+    def __init__(self, inner, log):
+        self.inner, self.log = inner, log
+
+    def set_player_ind(self, p):
+        self.inner.set_player_ind(p)
+        self.player = p
+
+    def get_action(self, board):
+        m = self.inner.get_action(board)
+        self.log.append(int(m))
+        return m
+
+
+def test_arena_games_match_reference(az):
+    """Game.start_play between the drop-in players, seeded like the reference's recorded games
+    (np.random.seed / random.seed): rollout player against rollout player, and the network player
+    in evaluation mode (HIP CNN, mcts_alphaZero.py:243-255) against the rollout player, which is the
+    pairing of TrainPipeline.policy_evaluate (train.py:216-276).  Moves, winner and the numpy
+    stream afterwards must be the reference's."""
+    import random
+    games = load("g8_pure.npz")["games"]
+    assert len(games) >= 8
+    for g in games:
+        n, k = int(g["n"]), int(g["k"])
+        log = []
+        if g["kind"] == "pure_vs_pure":
+            p1 = az.MCTS_Pure(c_puct=5, n_playout=int(g["n_playout1"]))
+        else:
+            net = az.PolicyValueNet(n, n)
+            net.load_numpy_params(helpers.make_params(n, seed=int(g["param_seed"])))
+            p1 = az.MCTSPlayer(net.policy_value_fn, c_puct=5, n_playout=int(g["n_playout1"]))
+        p2 = az.MCTS_Pure(c_puct=5, n_playout=int(g["n_playout2"]))
+        np.random.seed(int(g["seed"]))
+        random.seed(int(g["seed"]))
+        winner = az.Game(az.Board(width=n, height=n, n_in_row=k)).start_play(_Spy(p1, log), _Spy(p2, log),
+                                                                             start_player=int(g["start_player"]), is_shown=0)
+        assert log == [int(m) for m in g["moves"]], (g["kind"], n, int(g["start_player"]))
+        assert winner == g["winner"]
+        assert np.random.random_sample() == g["next_double"]
+
+
+def test_policy_evaluate_runs(az):
+    """TrainPipeline.policy_evaluate (train.py:216-276): win ratio of the current net against the
+    rollout player over alternating first moves."""
+    from alphazero_gomoku_amd.train import TrainPipeline
+    tp = TrainPipeline(board_width=6, board_height=6, n_in_row=4, n_playout=30, play_batch_size=1, pure_mcts_playout_num=40)
+    np.random.seed(1)
+    # the evaluation-mode opening of the reference (fixed 15x15 cells) applies to 15x15 boards only,
+    # so on 6x6 both colours are played out normally
+    ratio = tp.policy_evaluate(n_games=2)
+    assert 0.0 <= ratio <= 1.0 and sum(tp.last_win_cnt.values()) == 2

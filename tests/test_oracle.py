@@ -174,3 +174,88 @@ def test_config2_game_with_net(oracle):
     r = oracle.self_play(8, 5, "net", 5, 400, 1.0, int(g["seed"]), net=net)
     assert np.array_equal(r["visits"][0], g["visits"][0])
     assert r["moves"][0] == g["moves"][0]
+
+
+def _oracle_board(oracle, n, k, start_player, pre=()):
+    b = oracle.OracleBoard(n, n, k)
+    b.init_board(start_player)
+    for m in pre:
+        b.do_move(int(m))
+    return b
+
+
+def test_move_target_is_the_grown_bounding_box(oracle):
+    """Board.get_move_target (game.py:35-58): rows/columns 5..9 on an empty board, else the
+    stones' bounding box grown by two and clipped."""
+    assert _oracle_board(oracle, 6, 4, 0).move_target() == [35]
+    assert _oracle_board(oracle, 8, 5, 0).move_target() == [45, 46, 47, 53, 54, 55, 61, 62, 63]
+    b = _oracle_board(oracle, 8, 5, 0, [27])
+    assert b.move_target() == [r * 8 + c for r in range(1, 6) for c in range(1, 6) if r * 8 + c != 27]
+    b = _oracle_board(oracle, 8, 5, 0, [0, 63])
+    assert b.move_target() == [m for m in range(64) if m not in (0, 63)]
+    b = _oracle_board(oracle, 15, 5, 0, [112, 113])
+    assert b.move_target() == [r * 15 + c for r in range(5, 10) for c in range(5, 11) if r * 15 + c not in (112, 113)]
+
+
+def test_rollout_opponent_searches_match_reference(oracle):
+    """mcts_pure.MCTSPlayer searches recorded from the reference: move, root visit counts and
+    the position of the numpy stream afterwards, bit-exact."""
+    cases = load("g8_pure.npz")["cases"]
+    assert len(cases) >= 8
+    for c in cases:
+        n, k = int(c["n"]), int(c["k"])
+        b = _oracle_board(oracle, n, k, int(c["start_player"]), c["pre"])
+        rng = oracle.OracleRng(int(c["seed"]))
+        move, visits, root_visits = oracle.pure_get_move(b, float(c["c_puct"]), int(c["n_playout"]), rng)
+        assert move == c["move"] and root_visits == c["root_visits"], (n, int(c["seed"]))
+        assert np.array_equal(visits, c["visits"])
+        key, pos = rng.get_state()
+        assert pos == c["rng_pos"] and int(np.bitwise_xor.reduce(key)) == c["rng_key_crc"]
+        assert rng.random_sample() == c["next_double"]
+
+
+def _oracle_arena_game(oracle, g, max_plies=None):
+    """Game.start_play (game.py:211-290) between the players of a g8 game record, on the oracle."""
+    import random
+    n, k = int(g["n"]), int(g["k"])
+    b = _oracle_board(oracle, n, k, int(g["start_player"]))
+    rng = oracle.OracleRng(int(g["seed"]))
+    random.seed(int(g["seed"]))
+    az = None
+    if g["kind"] == "az_vs_pure":
+        net = oracle.OracleNet(n, n, helpers.make_params(n, seed=int(g["param_seed"])), precise=True)
+        az = oracle.OracleMCTS("net", 5, int(g["n_playout1"]), net=net)
+    moves = []
+    while True:
+        first = b.current_player == 1                    # player1 owns stone 1 (game.py:228-231)
+        if first and az is not None:
+            # MCTSPlayer.get_action in evaluation mode (mcts_alphaZero.py:243-255)
+            acts, _, _, _, probs = az.get_move_probs(b, 1e-3)
+            move = int(acts[helpers.choice_index(probs, rng.random_sample())])
+            if len(moves) == 0:
+                move = random.choice([96, 97, 98, 111, 112, 113, 126, 127, 128])
+            az.update_with_move(-1)
+        else:
+            move, _, _ = oracle.pure_get_move(b, 5, int(g["n_playout1"] if first else g["n_playout2"]), rng)
+        moves.append(move)
+        b.do_move(move)
+        end, winner = b.game_end()
+        if end or (max_plies and len(moves) >= max_plies):
+            return moves, winner, rng
+
+
+def test_arena_games_match_reference(oracle):
+    """Whole Game.start_play games recorded from the reference.  Rollout player against rollout
+    player: every move, the winner and the stream position.  Network player against rollout
+    player: the oracle's CPU net sums in another order than the reference's numpy net, so only
+    the opening (which includes the rollout player's first search) is required to agree."""
+    games = load("g8_pure.npz")["games"]
+    assert sum(g["kind"] == "pure_vs_pure" for g in games) >= 4 and sum(g["kind"] == "az_vs_pure" for g in games) >= 4
+    for g in games:
+        if g["kind"] == "pure_vs_pure":
+            moves, winner, rng = _oracle_arena_game(oracle, g)
+            assert moves == [int(m) for m in g["moves"]] and winner == g["winner"]
+            assert rng.random_sample() == g["next_double"]
+        else:
+            moves, _, _ = _oracle_arena_game(oracle, g, max_plies=2)
+            assert moves == [int(m) for m in g["moves"][:2]], (int(g["n"]), int(g["start_player"]))

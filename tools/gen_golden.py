@@ -473,7 +473,110 @@ def gen_equi():
     print("g6_equi written")
 
 
+# ---------------------------------------------------------------- G8 rollout opponent / arena
+def gen_pure():
+    """mcts_pure.MCTSPlayer (the rollout opponent of train.py:216-276) run by the reference:
+    single searches from given positions (move, root visit counts, position of the global numpy
+    stream afterwards) and whole Game.start_play games, rollout player against rollout player and
+    the AlphaZero player (numpy net, float32 convention, is_selfplay=0) against the rollout player."""
+    import contextlib
+    import io
+    import random
+    import mcts_pure as ref_pure
+
+    def quiet():
+        return contextlib.redirect_stdout(io.StringIO())
+
+    cases = []
+    specs = [
+        (8, 5, [], 1, 3, 200), (6, 4, [], 0, 1, 100), (8, 5, [27, 28, 35, 36, 20], 0, 7, 150),
+        (8, 5, [0, 63, 7, 56], 0, 11, 300), (9, 5, [40, 41, 31], 1, 2, 80),
+        (15, 5, [112, 113, 97, 98, 127], 0, 5, 60), (15, 5, [], 0, 6, 40),
+        (6, 4, [0, 1, 6, 7, 12, 13, 2, 8], 0, 9, 120),
+        (8, 5, [27, 0, 28, 1, 29, 2, 30, 3], 0, 4, 64),            # four in a row on the board: wins inside the tree
+        (6, 4, list(range(0, 30)), 0, 8, 50),                       # nearly full board
+        (8, 5, [36], 1, 12, 1000),                                  # train.py's pure_mcts_playout_num
+    ]
+    for (n, k, pre, sp, seed, npo) in specs:
+        b = ref_game.Board(width=n, height=n, n_in_row=k)
+        b.init_board(sp)
+        ok = True
+        for m in pre:
+            b.do_move(m)
+            if b.game_end()[0]:
+                ok = False
+        if not ok:
+            print("  skipped (position already ended):", n, k, pre)
+            continue
+        pl = ref_pure.MCTSPlayer(c_puct=5, n_playout=npo)
+        np.random.seed(seed)
+        with quiet():
+            mv = pl.mcts.get_move(b)
+        vis = np.zeros(n * n, dtype=np.int32)
+        for a, c in pl.mcts._root._children.items():
+            vis[a] = c._n_visits
+        st = np.random.get_state()
+        cases.append(dict(n=n, k=k, pre=np.array(pre, dtype=np.int32), start_player=sp, seed=seed, n_playout=npo,
+                          c_puct=5.0, move=int(mv), visits=vis, root_visits=int(pl.mcts._root._n_visits),
+                          rng_pos=int(st[2]), rng_key_crc=int(np.bitwise_xor.reduce(st[1])),
+                          next_double=float(np.random.random_sample())))
+        print("  pure case %dx%d npo=%d seed=%d -> move %d" % (n, n, npo, seed, mv))
+
+    class Spy:
+        """Forwards to a player and logs its moves (the reference's start_play keeps none)."""
+        def __init__(self, inner, log):
+            self.inner, self.log = inner, log
+
+        def set_player_ind(self, p):
+            self.inner.set_player_ind(p)
+            self.player = p
+
+        def get_action(self, board):
+            with quiet():
+                m = self.inner.get_action(board)
+            self.log.append(int(m))
+            return m
+
+    games = []
+    for (n, k, npo1, npo2, sp, seed) in [(6, 4, 60, 120, 0, 21), (6, 4, 60, 120, 1, 22), (8, 5, 100, 200, 0, 23), (8, 5, 150, 80, 1, 24)]:
+        log = []
+        np.random.seed(seed)
+        g = ref_game.Game(ref_game.Board(width=n, height=n, n_in_row=k))
+        w = g.start_play(Spy(ref_pure.MCTSPlayer(c_puct=5, n_playout=npo1), log), Spy(ref_pure.MCTSPlayer(c_puct=5, n_playout=npo2), log),
+                         start_player=sp, is_shown=0)
+        games.append(dict(kind="pure_vs_pure", n=n, k=k, n_playout1=npo1, n_playout2=npo2, start_player=sp, seed=seed,
+                          moves=np.array(log, dtype=np.int32), winner=int(w), next_double=float(np.random.random_sample())))
+        print("  pure vs pure %dx%d start %d: %d plies winner %d" % (n, n, sp, len(log), w))
+
+    # AlphaZero player (evaluation mode) against the rollout player.  The reference's evaluation-mode
+    # get_action replaces the first move on an EMPTY board by one of nine 15x15 centre cells
+    # (mcts_alphaZero.py:251-253), which is an illegal cell on smaller boards, so the games in which
+    # the AlphaZero player opens are 15x15 only.
+    for (n, k, pseed, npo_az, npo_pure, sp, seed) in [(6, 4, 106, 100, 150, 1, 31), (8, 5, 108, 120, 200, 1, 32),
+                                                      (15, 5, 115, 30, 40, 0, 33), (15, 5, 115, 30, 40, 1, 34)]:
+        net = ref_np_net.PolicyValueNetNumpy(n, n, helpers.torch_to_theano_layout(helpers.make_params(n, seed=pseed)))
+
+        def cb_net(board, net=net):
+            ap, v = net.policy_value_fn(board)
+            return [(a, float(np.float32(p))) for a, p in ap], float(np.float32(v))
+        log = []
+        np.random.seed(seed)
+        random.seed(seed)
+        g = ref_game.Game(ref_game.Board(width=n, height=n, n_in_row=k))
+        az = ref_mcts.MCTSPlayer(cb_net, c_puct=5, n_playout=npo_az)
+        w = g.start_play(Spy(az, log), Spy(ref_pure.MCTSPlayer(c_puct=5, n_playout=npo_pure), log), start_player=sp, is_shown=0)
+        games.append(dict(kind="az_vs_pure", n=n, k=k, param_seed=pseed, n_playout1=npo_az, n_playout2=npo_pure, start_player=sp,
+                          seed=seed, moves=np.array(log, dtype=np.int32), winner=int(w),
+                          next_double=float(np.random.random_sample())))
+        print("  az vs pure %dx%d start %d: %d plies winner %d" % (n, n, sp, len(log), w))
+    np.savez_compressed(os.path.join(OUT, "g8_pure.npz"), cases=np.array(cases, dtype=object), games=np.array(games, dtype=object))
+    print("g8_pure written: %d cases, %d games" % (len(cases), len(games)))
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "pure":
+        gen_pure()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "equi":
         gen_equi()
         sys.exit(0)
@@ -489,4 +592,5 @@ if __name__ == "__main__":
     gen_games(helpers.make_params(6, seed=106))
     gen_equi()
     gen_net_game8()
+    gen_pure()
     print("done ->", OUT)
