@@ -105,11 +105,20 @@ class TrainPipeline:
         return loss, entropy
 
     # ---- train.py:216-276 --------------------------------------------------------------------
-    def policy_evaluate(self, n_games=10):
+    def policy_evaluate(self, n_games=10, batched=False, seed0=0):
         """Play the current policy (evaluation mode: no exploration noise, fresh tree per move)
         against the rollout MCTS player, sides alternating, and return the win ratio
-        (wins + half the ties) / n_games.  Only for monitoring the progress of training."""
+        (wins + half the ties) / n_games.  Only for monitoring the progress of training.
+        batched=False plays the games one after another on numpy's global stream, like the
+        reference; batched=True plays them side by side on the GPU, game i on its own streams
+        seeded seed0 + i (arena.play_arena_games)."""
         from collections import defaultdict
+        if batched:
+            from .arena import play_arena_games, win_ratio
+            recs = play_arena_games(self.policy_value_net, n_games, self.board_width, self.n_in_row, self.n_playout,
+                                    self.pure_mcts_playout_num, self.c_puct, seed0, self.device)
+            self.last_win_cnt = {w: sum(r["winner"] == w for r in recs) for w in (1, 2, -1)}
+            return win_ratio(recs)
         from .mcts import MCTSPlayer
         from .mcts_pure import MCTSPlayer as MCTS_Pure
         current_mcts_player = MCTSPlayer(self.policy_value_net.policy_value_fn, c_puct=self.c_puct,

@@ -583,3 +583,25 @@ def test_policy_evaluate_runs(az):
     # so on 6x6 both colours are played out normally
     ratio = tp.policy_evaluate(n_games=2)
     assert 0.0 <= ratio <= 1.0 and sum(tp.last_win_cnt.values()) == 2
+
+
+def test_batched_arena_equals_seeded_dropin_games(az):
+    """arena.play_arena_games: game i of the batch is the game the drop-in players produce after
+    np.random.seed(seed0 + i); random.seed(seed0 + i), with start_player = i % 2."""
+    import random
+    from alphazero_gomoku_amd.arena import play_arena_games, win_ratio
+    n, k, npo, pure = 6, 4, 40, 60
+    net = az.PolicyValueNet(n, n)
+    net.load_numpy_params(helpers.make_params(n, seed=106))
+    recs = play_arena_games(net, 5, n, k, npo, pure, 5.0, seed0=70)
+    assert [r["game"] for r in recs] == [0, 1, 2, 3, 4] and 0.0 <= win_ratio(recs) <= 1.0
+    for r in recs:
+        log = []
+        p1 = az.MCTSPlayer(net.policy_value_fn, c_puct=5, n_playout=npo)
+        p2 = az.MCTS_Pure(c_puct=5, n_playout=pure)
+        np.random.seed(70 + r["game"])
+        random.seed(70 + r["game"])
+        winner = az.Game(az.Board(width=n, height=n, n_in_row=k)).start_play(_Spy(p1, log), _Spy(p2, log),
+                                                                             start_player=r["start_player"], is_shown=0)
+        assert r["start_player"] == r["game"] % 2
+        assert log == r["moves"] and winner == r["winner"], r["game"]
