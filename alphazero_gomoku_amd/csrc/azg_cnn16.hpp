@@ -218,6 +218,33 @@ __device__ inline void conv3x3_f16(const half8 *wp, WRing<RING> &ring, const cha
         if (sub * PT + i < G::NT) epi(i, sub * PT + i, acc[i], prow[i], ctx);   // wave-uniform: epilogues may use MFMA
 }
 
+// Wave-wide float reductions on the DPP network (lane^1, lane^2, mirror within 8, mirror within
+// 16, then one lane of each row of 16): register-to-register, where a __shfl_xor butterfly costs
+// six LDS-crossbar round trips.  All 64 lanes must be active; the result is wave-uniform.
+template <int CTRL>
+__device__ inline float dpp_f32(float v)
+{
+    const int b = __float_as_int(v);
+    return __int_as_float(__builtin_amdgcn_update_dpp(b, b, CTRL, 0xF, 0xF, false));
+}
+__device__ inline float lane_f32(float v, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane)); }
+__device__ inline float wave_max_f32(float v)
+{
+    v = fmaxf(v, dpp_f32<0xB1>(v));
+    v = fmaxf(v, dpp_f32<0x4E>(v));
+    v = fmaxf(v, dpp_f32<0x141>(v));
+    v = fmaxf(v, dpp_f32<0x140>(v));
+    return fmaxf(fmaxf(lane_f32(v, 0), lane_f32(v, 16)), fmaxf(lane_f32(v, 32), lane_f32(v, 48)));
+}
+__device__ inline float wave_sum_f32(float v)
+{
+    v += dpp_f32<0xB1>(v);
+    v += dpp_f32<0x4E>(v);
+    v += dpp_f32<0x141>(v);
+    v += dpp_f32<0x140>(v);
+    return (lane_f32(v, 0) + lane_f32(v, 16)) + (lane_f32(v, 32) + lane_f32(v, 48));
+}
+
 // One group of 32-output tiles of a fully connected layer for one wave: NTG tiles, the wave's
 // KW k-steps of each.  Units (k-step, tile) stream through a ring of RU register pairs.
 template <int NTG, int KW>
@@ -397,16 +424,14 @@ __device__ inline void cnn16_tail(const NetWeights &nw, float *lds, int tid, Pro
             x[i] = a < G::S ? fc_out(a, lb[G::B_PFC + a]) : -3.0e38f;
             mx = fmaxf(mx, x[i]);
         }
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+        mx = wave_max_f32(mx);
         float sum = 0.0f;
 #pragma unroll
         for (int i = 0; i < PER; i++) {
             const int a = lane + 64 * i;
             if (a < G::S) sum += expf(x[i] - mx);
         }
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off);
+        sum = wave_sum_f32(sum);
         const float lse = logf(sum);
 #pragma unroll
         for (int i = 0; i < PER; i++) {
@@ -416,8 +441,7 @@ __device__ inline void cnn16_tail(const NetWeights &nw, float *lds, int tid, Pro
         float hdn = fc_out(G::OTP * 32 + lane, lb[G::B_VFC1 + lane]);
         hdn = hdn > 0.0f ? hdn : 0.0f;
         float v = hdn * lb[G::B_WVFC2 + lane];
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+        v = wave_sum_f32(v);
         if (lane == 0) lds[G::VAL_OFF + leaf] = tanhf(v + lb[G::B_VFC2]);
     }
     __syncthreads();
