@@ -605,3 +605,74 @@ def test_batched_arena_equals_seeded_dropin_games(az):
                                                                              start_player=r["start_player"], is_shown=0)
         assert r["start_player"] == r["game"] % 2
         assert log == r["moves"] and winner == r["winner"], r["game"]
+
+
+def _check_step_invariants(n, n_playout, visits, root_n, carried, pi, occupied, live):
+    """Properties every move step has, whatever the size: the root was visited once per playout
+    on top of what the re-used subtree carried over, all but the expanding visit went to a
+    child, no visit and no probability sits on an occupied cell, pi sums to one."""
+    assert np.array_equal(root_n[live], carried[live] + n_playout)
+    assert np.array_equal(visits[live].sum(axis=1), root_n[live] - 1)
+    assert not (visits[live] * occupied[live]).any()
+    assert not (pi[live] * occupied[live]).any()
+    np.testing.assert_allclose(pi[live].sum(axis=1), 1.0, rtol=0, atol=1e-12)
+
+
+@pytest.mark.parametrize("n,k,n_playout,B,steps", [(8, 5, 400, 1024, 36), (15, 5, 800, 512, 2)],
+                         ids=["C2-8x8-400-1024", "C4-15x15-800-512"])
+def test_full_size_configurations_keep_the_invariants(az, n, k, n_playout, B, steps):
+    """The benchmark's full sizes (1024 games of 8x8 / 400 playouts; 512 games of 15x15 / 800
+    playouts) with the CNN as leaf evaluator: per-step invariants for every slot, the training
+    tuples of finished games, and slots spread over the batch against the same seeds played alone."""
+    eng = az.SelfPlayEngine(n, k, n_playout, B, 5.0)
+    params = helpers.make_params(n, seed=100 + n)
+    eng.set_weights(params)
+    seeds = np.arange(B, dtype=np.uint32) + 500
+    eng.reset_games(seeds=seeds)
+    S = n * n
+    occupied = np.zeros((B, S), dtype=bool)
+    carried = np.zeros(B, dtype=np.int64)
+    history = [[] for _ in range(B)]
+    live = np.ones(B, dtype=bool)
+    for t in range(steps):
+        eng.search()
+        visits, _, _, root_n = eng.root_stats()
+        moves, pi = eng.sample_and_advance(1.0)
+        _check_step_invariants(n, n_playout, visits, root_n.astype(np.int64), carried, pi, occupied, live)
+        idx = np.nonzero(live)[0]
+        assert (moves[idx] >= 0).all() and not occupied[idx, moves[idx]].any()
+        assert (moves[~live] == -1).all()
+        carried[idx] = visits[idx, moves[idx]]
+        occupied[idx, moves[idx]] = True
+        for g in idx:
+            history[g].append(int(moves[g]))
+        ended, winner, plies = eng.status()
+        assert np.array_equal(plies, occupied.sum(axis=1))
+        live = ~ended
+    ended, winner, plies = eng.status()
+    if ended.any():
+        s = eng.drain_samples()
+        assert len(s["z"]) == int(plies[ended].sum())
+        for g in np.nonzero(ended)[0]:
+            sel = s["game_id"] == g
+            order = np.argsort(s["ply"][sel])
+            z, st = s["z"][sel][order], s["states"][sel][order]
+            assert len(z) == plies[g] and np.array_equal(s["ply"][sel][order], np.arange(plies[g]))
+            mover = 1 + (np.arange(plies[g]) % 2)                         # stone 1 opens
+            want = np.zeros(plies[g]) if winner[g] == -1 else np.where(mover == winner[g], 1.0, -1.0)
+            assert np.array_equal(z, want.astype(np.float32))
+            # stones on the planes = plies played before the move; colour plane = parity
+            assert np.array_equal(st[:, 0].sum(axis=(1, 2)) + st[:, 1].sum(axis=(1, 2)), np.arange(plies[g]))
+            assert np.array_equal(st[:, 3, 0, 0], (np.arange(plies[g]) % 2 == 0).astype(np.float32))
+    eng.close()
+    # the same seeds played alone give the same games (slots do not influence each other)
+    check = min(steps, 3)
+    for g in (0, B // 2 + 1, B - 1):
+        one = az.SelfPlayEngine(n, k, n_playout, 1, 5.0)
+        one.set_weights(params)
+        one.reset_games(seeds=seeds[g:g + 1])
+        for t in range(min(check, len(history[g]))):
+            one.search()
+            mv, _ = one.sample_and_advance(1.0, want_pi=False)
+            assert mv[0] == history[g][t], (g, t)
+        one.close()
