@@ -153,3 +153,68 @@ class TrainPipeline:
                         self.pure_mcts_playout_num += 1000
                         self.best_win_ratio = 0.0
         return self.policy_value_net
+
+
+def main(argv=None):
+    """The training loop as a program: `python -m alphazero_gomoku_amd.train --games 3000` on one
+    GPU, or under `python -m torch.distributed.run --nproc-per-node N` with one rank per GPU
+    (games shard by id over the ranks, tuples are gathered over RCCL, the policy update is
+    data-parallel).  Rank 0 prints one JSON line with what was played and learned."""
+    import argparse
+    import json
+    import os
+    import time
+    ap = argparse.ArgumentParser(description=main.__doc__)
+    ap.add_argument("--board", type=int, default=8)
+    ap.add_argument("--n-in-row", type=int, default=5)
+    ap.add_argument("--playouts", type=int, default=400)
+    ap.add_argument("--games", type=int, default=3000, help="self-play games in total")
+    ap.add_argument("--play-batch", type=int, default=1024, help="games per self-play batch (all ranks together)")
+    ap.add_argument("--batch-size", type=int, default=512)
+    ap.add_argument("--buffer-size", type=int, default=200000)
+    ap.add_argument("--epochs", type=int, default=5)
+    ap.add_argument("--lr", type=float, default=2e-3)
+    ap.add_argument("--check-freq", type=int, default=0, help="evaluate against the rollout player every this many batches (0 = never)")
+    ap.add_argument("--pure-playouts", type=int, default=1000)
+    ap.add_argument("--save", default=None, help="write the final state_dict here")
+    args = ap.parse_args(argv)
+    os.environ.setdefault("NCCL_DEBUG", "WARN")            # keeps most of RCCL's start-up banner off stdout
+    import torch
+    import torch.distributed as dist
+    rank, world, local = 0, 1, int(os.environ.get("LOCAL_RANK", "0"))
+    if "RANK" in os.environ:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        rank, world = dist.get_rank(), dist.get_world_size()
+    torch.manual_seed(0)                                   # every rank starts from the same weights
+    random.seed(1234)                                      # and samples the same mini-batches
+    per_rank = max(1, (args.play_batch + world - 1) // world)
+    tp = TrainPipeline(board_width=args.board, board_height=args.board, n_in_row=args.n_in_row, learn_rate=args.lr,
+                       n_playout=args.playouts, buffer_size=args.buffer_size, batch_size=args.batch_size,
+                       play_batch_size=args.play_batch, epochs=args.epochs, check_freq=args.check_freq,
+                       game_batch_num=(args.games + args.play_batch - 1) // args.play_batch, n_parallel=per_rank,
+                       device=local, pure_mcts_playout_num=args.pure_playouts)
+    if world > 1:
+        from . import dist as azdist
+        azdist.broadcast_weights(tp.policy_value_net)
+    log = []
+    t0 = time.perf_counter()
+    tp.run(on_batch=lambda i, n, loss, ent: log.append((i, n, loss, ent)))
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if rank == 0:
+        if args.save:
+            tp.policy_value_net.save_model(args.save)
+        losses = [l for _, _, l, _ in log if l is not None]
+        print(json.dumps({"games": tp.games_played, "ranks": world, "seconds": dt, "games_per_s_incl_training": tp.games_played / dt,
+                          "samples": int(sum(n for _, n, _, _ in log)), "policy_updates": len(losses),
+                          "first_loss": losses[0] if losses else None, "last_loss": losses[-1] if losses else None,
+                          "lr_multiplier": tp.lr_multiplier, "best_win_ratio": tp.best_win_ratio}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
