@@ -676,3 +676,34 @@ def test_full_size_configurations_keep_the_invariants(az, n, k, n_playout, B, st
             mv, _ = one.sample_and_advance(1.0, want_pi=False)
             assert mv[0] == history[g][t], (g, t)
         one.close()
+
+
+@pytest.mark.parametrize("n,k", [(7, 4), (10, 5), (16, 5)])
+def test_rollout_opponent_other_boards_and_unaligned_stream(az, oracle, n, k):
+    """Board sizes without a fixture (7x7, 10x10 and the largest supported, 16x16) against the
+    oracle, starting from a stream position that is odd and in the middle of a generator block
+    (the host program drew other numbers before), so doubles straddle the block refresh."""
+    npo = 70
+    rs = np.random.RandomState(n)
+    rs.bytes(4 * 333)                                          # 333 generator words: odd position
+    st = rs.get_state()
+    assert st[2] % 2 == 1
+    pre = [(n // 2) * n + n // 2, (n // 2) * n + n // 2 + 1, (n // 2 + 1) * n + n // 2]
+    eng = az.SelfPlayEngine(n, k, npo, 1, 5.0, prior_mode=az.PRIOR_UNIFORM32, arena_nodes=npo + 8)
+    eng.reset_games()
+    eng.set_position(0, stones_of(pre, 1), pre[-1], 2)
+    words = np.empty((1, 625), dtype=np.uint32)
+    words[0, :624], words[0, 624] = st[1], st[2]
+    moves = eng.pure_search(npo, words)
+    visits, _, _, root_n = eng.root_stats()
+    b = oracle.OracleBoard(n, n, k)
+    b.init_board(0)
+    for m in pre:
+        b.do_move(m)
+    rng = oracle.OracleRng(0)
+    rng.set_state(st[1], st[2])
+    mv, vis, rn = oracle.pure_get_move(b, 5.0, npo, rng)
+    key, pos = rng.get_state()
+    assert moves[0] == mv and root_n[0] == rn and np.array_equal(visits[0], vis)
+    assert int(words[0, 624]) == pos and np.array_equal(words[0, :624], key)
+    eng.close()
