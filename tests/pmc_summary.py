@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 --pmc runs of bench.py: per counter, the mean over the last launches of
+the search kernel (steady state).  Usage: python tests/pmc_summary.py OUT.json DIR [DIR ...]
+where every DIR holds a *_counter_collection.csv of one pass."""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+
+def main():
+    out_path, dirs = sys.argv[1], sys.argv[2:]
+    res = {}
+    for d in dirs:
+        for path in glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True):
+            per = defaultdict(lambda: defaultdict(float))          # counter -> dispatch -> value
+            with open(path, newline="") as f:
+                for row in csv.DictReader(f):
+                    if "search_kernel" not in row["Kernel_Name"]:
+                        continue
+                    per[row["Counter_Name"]][int(row["Dispatch_Id"])] += float(row["Counter_Value"])
+            for name, by_dispatch in per.items():
+                ids = sorted(by_dispatch)
+                last = ids[-4:]
+                res[name] = {"launches": len(ids), "mean_of_last_4": sum(by_dispatch[i] for i in last) / len(last)}
+    with open(out_path, "w") as f:
+        json.dump(res, f, indent=1)
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()
