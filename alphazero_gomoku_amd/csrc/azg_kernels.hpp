@@ -44,8 +44,14 @@ __device__ inline void net_prepare(const NetWeights &nw, float *smem)
 
 // The split-f16 kernels for boards up to 8x8 need < 80 KB of LDS; two waves per SIMD (second
 // launch-bound argument) lets two workgroups share a CU.
+#ifndef AZG_OCC8
+#define AZG_OCC8 2      // workgroups per CU the split-f16 kernels for boards up to 8x8 are built for
+#endif
+#ifndef AZG_GATE8
+#define AZG_GATE8 1     // per-CU matrix gate for those kernels
+#endif
 template <int N, int T, int MODE, bool F16>
-__global__ __launch_bounds__(256, (F16 && MODE == 0 && N <= 8) ? 2 : 1) void search_kernel(DevState st)
+__global__ __launch_bounds__(256, (F16 && MODE == 0 && N <= 8) ? AZG_OCC8 : 1) void search_kernel(DevState st)
 {
     using G = typename GeomPick<(MODE == 0 ? N : 4), (MODE == 0 ? T : 1), F16>::type;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -87,7 +93,7 @@ __global__ __launch_bounds__(256, (F16 && MODE == 0 && N <= 8) ? 2 : 1) void sea
     wave_sync();
     long long n_eval = 0;
     MatrixGate gate;
-    gate.init(F16 && MODE == 0 && N <= 8);
+    gate.init(F16 && MODE == 0 && N <= 8 && AZG_GATE8);
     Prof prof;
     prof.start(st.stamps);
 

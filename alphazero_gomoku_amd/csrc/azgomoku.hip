@@ -127,6 +127,9 @@ static SearchLaunch net_launch()
     return {search_kernel<N, T, 0, F16>, T, (size_t)G::END * 4 + T * sizeof(GameLdsT<N * N + 1>)};
 }
 
+#ifndef AZG_T8
+#define AZG_T8 2        // games per workgroup of the split-f16 8x8 search kernel
+#endif
 static bool pick_search(int N, int mode, int cnn_mode, SearchLaunch *out)
 {
     if (mode == AZG_PRIOR_UNIFORM32) { *out = {search_kernel<0, 4, 1, false>, 4, 4 * sizeof(GameLds)}; return true; }
@@ -134,7 +137,7 @@ static bool pick_search(int N, int mode, int cnn_mode, SearchLaunch *out)
     const bool f16 = cnn_mode == AZG_CNN_F16X3;
     switch (N) {
     case 6: *out = f16 ? net_launch<6, 2, true>() : net_launch<6, 2, false>(); return true;
-    case 8: *out = f16 ? net_launch<8, 2, true>() : net_launch<8, 2, false>(); return true;
+    case 8: *out = f16 ? net_launch<8, AZG_T8, true>() : net_launch<8, 2, false>(); return true;
     case 15: *out = f16 ? net_launch<15, 1, true>() : net_launch<15, 1, false>(); return true;
     default: return false;
     }

@@ -17,6 +17,25 @@ PARAM_ORDER = ["conv1.weight", "conv1.bias", "conv2.weight", "conv2.bias", "conv
                "val_fc2.weight", "val_fc2.bias"]
 
 
+def theano_to_torch_layout(params):
+    """The 16-tensor list of the reference's Theano/Lasagne and numpy nets
+    (policy_value_net_numpy.py:103-113: convolution kernels stored for a true convolution, i.e.
+    rotated by 180 degrees, fully connected matrices as (in, out)) -> the PyTorch state_dict
+    layout of PARAM_ORDER.  The mapping is its own inverse up to the transposes."""
+    out = []
+    for p in params:
+        p = np.asarray(p, dtype=np.float32)
+        if p.ndim == 4:
+            p = p[:, :, ::-1, ::-1]
+        elif p.ndim == 2:
+            p = p.T
+        out.append(np.array(p, dtype=np.float32, order="C", copy=True))
+    return out
+
+
+torch_to_theano_layout = theano_to_torch_layout          # flips and transposes undo themselves
+
+
 class Net(nn.Module):
     """Parameter container with the reference's module names, so state_dicts interchange
     (policy_value_net_pytorch.py:23-41).  forward() exists for autograd in train_step."""
@@ -56,9 +75,9 @@ class PolicyValueNet(object):
         self.device = torch.device("cuda", device)
         self.policy_value_net = Net(board_width, board_height).to(self.device)
         self.optimizer = torch.optim.Adam(self.policy_value_net.parameters(), weight_decay=self.l2_const)
-        if model_file:
-            self.policy_value_net.load_state_dict(torch.load(model_file, map_location=self.device, weights_only=True))
         self.version = 0          # bumped whenever the parameters change
+        if model_file:
+            self.load_model(model_file)
         self.data_parallel = False   # True: train_step averages gradients over torch.distributed ranks
         self._eval_engine = None
         self._eval_version = -1
@@ -72,8 +91,41 @@ class PolicyValueNet(object):
         """16 float32 arrays in the state_dict order above."""
         sd = self.policy_value_net.state_dict()
         for k, p in zip(PARAM_ORDER, params):
-            sd[k].copy_(torch.from_numpy(np.ascontiguousarray(p, dtype=np.float32)).reshape(sd[k].shape))
+            # a real copy: a flipped 1x1 kernel counts as contiguous for numpy but keeps negative strides
+            sd[k].copy_(torch.from_numpy(np.array(p, dtype=np.float32, order="C", copy=True)).reshape(sd[k].shape))
         self.version += 1
+
+    def load_model(self, model_file, layout=None):
+        """A PyTorch state_dict file (what save_model and the reference's PyTorch net write,
+        policy_value_net_pytorch.py:150-157), or an .npz archive of the 16 parameter arrays
+        (arr_0..arr_15) in the PyTorch layout or, with layout='theano' (or a 'layout' entry in
+        the archive saying so), in the layout of the reference's Theano/numpy model files.
+        Files are read with loaders that execute nothing from them (weights_only=True,
+        allow_pickle=False); a pickled Theano model has to be converted where it is trusted:
+        np.savez(path, *pickle.load(open(model, 'rb'), encoding='bytes'), layout='theano')."""
+        if str(model_file).endswith(".npz"):
+            with np.load(model_file, allow_pickle=False) as z:
+                if layout is None and "layout" in z.files:
+                    layout = str(z["layout"])
+                params = [z["arr_%d" % i] for i in range(16)]
+            if layout == "theano":
+                params = theano_to_torch_layout(params)
+            elif layout not in (None, "torch"):
+                raise ValueError("layout must be 'torch' or 'theano'")
+            self.load_numpy_params(params)
+        else:
+            self.policy_value_net.load_state_dict(torch.load(model_file, map_location=self.device, weights_only=True))
+            self.version += 1
+
+    def save_numpy(self, path, layout="torch"):
+        """The 16 parameter arrays as an .npz archive (see load_model); layout='theano' writes what
+        policy_value_net_numpy.PolicyValueNetNumpy consumes."""
+        params = [t.detach().cpu().numpy() for t in self.param_tensors()]
+        if layout == "theano":
+            params = torch_to_theano_layout(params)
+        elif layout != "torch":
+            raise ValueError("layout must be 'torch' or 'theano'")
+        np.savez(path, *params, layout=layout)
 
     def sync_engine(self, engine, have_version):
         """Push the parameters into `engine` if it holds an older copy; returns the version."""

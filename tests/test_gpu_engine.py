@@ -707,3 +707,37 @@ def test_rollout_opponent_other_boards_and_unaligned_stream(az, oracle, n, k):
     assert moves[0] == mv and root_n[0] == rn and np.array_equal(visits[0], vis)
     assert int(words[0, 624]) == pos and np.array_equal(words[0, :624], key)
     eng.close()
+
+
+def test_weight_files_in_both_layouts(az, oracle, tmp_path):
+    """Weight interchange (policy_value_net_pytorch.py:150-157, policy_value_net_numpy.py:103-113):
+    a state_dict file and .npz archives in the PyTorch and in the Theano layout all load into the
+    same network, whose HIP forward pass matches the oracle's net on the original arrays."""
+    n = 8
+    params = helpers.make_params(n, seed=108)
+    net = az.PolicyValueNet(n, n)
+    net.load_numpy_params(params)
+    f_sd, f_t, f_th = tmp_path / "m.model", tmp_path / "torch.npz", tmp_path / "theano.npz"
+    net.save_model(str(f_sd))
+    net.save_numpy(str(f_t), layout="torch")
+    net.save_numpy(str(f_th), layout="theano")
+    with np.load(str(f_th)) as z:
+        th = [z["arr_%d" % i] for i in range(16)]
+    for a, b in zip(th, helpers.torch_to_theano_layout(params)):
+        assert np.array_equal(a, b)
+    board = az.Board(width=n, height=n, n_in_row=5)
+    board.init_board()
+    for m in (27, 28, 36):
+        board.do_move(m)
+    st = board.current_state()[None]
+    po, vo = oracle.OracleNet(n, n, params, precise=True).forward(board.current_state())
+    for f in (f_sd, f_t, f_th):
+        other = az.PolicyValueNet(n, n, model_file=str(f))
+        probs, vals = other.policy_value(st)
+        assert np.abs(probs[0] - po).max() < 1e-5 and abs(vals[0, 0] - vo) < 1e-5, f
+    # the engine takes the Theano layout directly as well
+    eng = az.SelfPlayEngine(n, 5, 10, 1, 5.0)
+    eng.set_weights(th, layout=az._lib.LAYOUT_THEANO)
+    probs, vals = eng.eval_batch(st.astype(np.float32))
+    assert np.abs(probs[0] - po).max() < 1e-5
+    eng.close()
