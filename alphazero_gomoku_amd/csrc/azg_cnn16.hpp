@@ -245,12 +245,15 @@ __device__ inline float wave_sum_f32(float v)
     return (lane_f32(v, 0) + lane_f32(v, 16)) + (lane_f32(v, 32) + lane_f32(v, 48));
 }
 
+#ifndef AZG_FC_RING
+#define AZG_FC_RING 28        // weight units (k-step, tile) of a fully connected layer in flight per wave
+#endif
 // One group of 32-output tiles of a fully connected layer for one wave: NTG tiles, the wave's
 // KW k-steps of each.  Units (k-step, tile) stream through a ring of RU register pairs.
 template <int NTG, int KW>
 struct FcRing {
     static constexpr int NU = NTG * KW;
-    static constexpr int RU = NU < 12 ? NU : 12;
+    static constexpr int RU = NU < AZG_FC_RING ? NU : AZG_FC_RING;
     half8 ah[RU], al[RU];
 };
 
