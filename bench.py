@@ -118,8 +118,23 @@ def main():
     run = SelfPlayRunner(eng, temp=1.0, seed0=0, first_game_id=rank, game_id_stride=world,
                          total=None, on_samples=drained.append, device_samples=True, pipelined=not args.host_refill)
     run.start()
+
+    def gather_all(chunks):
+        # the (state, pi, z) gather of the sharded configuration: every rank ends up with every
+        # rank's tuples (RCCL all_gather over xGMI)
+        if chunks:
+            mine = {key: torch.cat([d[key] for d in chunks]) for key in ("states", "pi", "z", "game_id", "ply")}
+        else:
+            mine = {"states": torch.empty((0, 4, n, n), dtype=torch.float32, device=dev), "pi": torch.empty((0, n * n), dtype=torch.float64, device=dev),
+                    "z": torch.empty(0, device=dev), "game_id": torch.empty(0, dtype=torch.int64, device=dev),
+                    "ply": torch.empty(0, dtype=torch.int32, device=dev)}
+        mine["states"] = mine["states"].to(torch.uint8)   # the planes are 0/1: exact, a quarter of the bytes on the links
+        return int(azdist.gather_samples(mine)["z"].shape[0])
+
     for _ in range(args.warmup):
         run.step()
+    if use_dist:
+        gather_all(drained)          # warm-up of the exchange too: RCCL sets its channels up on first use
     drained.clear()
     eng.profile()                                   # reset the kernel timers
     if use_dist:
@@ -131,17 +146,7 @@ def main():
         run.step()
     gathered = 0
     if use_dist:
-        # the (state, pi, z) gather of the sharded configuration: every rank ends up with
-        # every rank's tuples of the timed region (RCCL all_gather over xGMI)
-        if drained:
-            mine = {key: torch.cat([d[key] for d in drained]) for key in ("states", "pi", "z", "game_id", "ply")}
-        else:
-            mine = {"states": torch.empty((0, 4, n, n), dtype=torch.float32, device=dev), "pi": torch.empty((0, n * n), dtype=torch.float64, device=dev),
-                    "z": torch.empty(0, device=dev), "game_id": torch.empty(0, dtype=torch.int64, device=dev),
-                    "ply": torch.empty(0, dtype=torch.int32, device=dev)}
-        mine["states"] = mine["states"].to(torch.uint8)   # the planes are 0/1: exact, a quarter of the bytes on the links
-        allt = azdist.gather_samples(mine)
-        gathered = int(allt["z"].shape[0])
+        gathered = gather_all(drained)                      # the tuples of the timed region, inside the timed region
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
