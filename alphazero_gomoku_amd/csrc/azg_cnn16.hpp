@@ -68,6 +68,16 @@ struct Cnn16Geom {
     static constexpr int VAL_OFF = LG_OFF + T_ * S;           // values [T]
     static constexpr int X_OFF = HP_OFF + 32 * NTP;           // head outputs as halves: hi [T][KPP], lo [T][KPP], hi [T][KPV], lo [T][KPV]
     static constexpr int X_END = X_OFF + T_ * (KPP + KPV);
+    // One-leaf kernels (T == 1): the fully connected layers run on the VALU over the NON-ZERO head
+    // outputs only.  Wave w owns the inputs k = 4*i + w; its (k, x) pairs sit in lists behind the
+    // head partials, the per-wave partial sums in the (by then dead) head-partial region.
+    static constexpr bool SPARSE_FC = T_ == 1;
+    static constexpr int QP = S, QV = (2 * S + 3) / 4;        // list capacities per wave: policy, value
+    static constexpr int LP_OFF = X_OFF, LV_OFF = LP_OFF + 2 * 4 * QP, CNT_OFF = LV_OFF + 2 * 4 * QV, SP_END = CNT_OFF + 8;
+    static constexpr int SPP_OFF = 0;                         // policy partials [4 waves][256]
+    static constexpr int SPV_OFF = 2048;                      // value partials [4 waves][4 lane groups][64]
+    static_assert(!SPARSE_FC || (S <= 256 && LG_OFF >= SPP_OFF + 1024 && VAL_OFF < SPV_OFF && SPV_OFF + 1024 <= X_OFF && SP_END * 4 <= A2H_OFF),
+                  "sparse FC scratch does not fit");
     static_assert(VAL_OFF + T_ <= X_OFF, "FC partials and results must fit in the head-partial region");
     static_assert(X_END * 4 <= A2H_OFF, "scratch does not fit under IN+A1");
     static_assert(T_ <= 4, "one wave per position in the softmax stage");
@@ -311,6 +321,137 @@ __device__ inline void fc16_run(gptr<half8> w, int ks_total, FcRing<NTG, KW> &r,
 #pragma unroll
             for (int t = 0; t < T; t++) out[(i * 32 + n) * T + t] = acc[i][t];
     }
+}
+
+// The tail of a one-leaf forward pass (T == 1, the 15x15 kernels): head outputs, then both wide
+// fully connected layers as sparse matrix-vector products on the VALU.  With one leaf the FC
+// layers are bound by streaming their weights from L2 (0.8 MB for 15x15), and about half of the
+// ReLU'd head outputs are exactly zero: only the weight rows of non-zero inputs are read.
+// Wave w compacts and multiplies the inputs k = 4*i + w; a lane owns four consecutive outputs
+// (16-byte loads, 16 rows in flight per wave).  Sums are float32 in a fixed order.
+template <class G>
+__device__ inline void cnn16_tail_sparse(const NetWeights &nw, float *lds, int tid, Prof &prof)
+{
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const float *lb = lds + G::BIAS_OFF / 4;
+    struct Pair { int k; float x; };
+    Pair *lp = reinterpret_cast<Pair *>(lds + G::LP_OFF) + wave * G::QP;
+    Pair *lv = reinterpret_cast<Pair *>(lds + G::LV_OFF) + wave * G::QV;
+    int *cnt = reinterpret_cast<int *>(lds + G::CNT_OFF);
+
+    // ---- head outputs (bias + the four channel-tile partials, ReLU) and their non-zero lists
+    auto compact = [&](int kmax, int c0, Pair *list) {
+        const float *bh = lb + G::B_HEAD;
+        int n = 0;
+        for (int i0 = 0; 4 * i0 + wave < kmax; i0 += WAVE) {
+            const int k = 4 * (i0 + lane) + wave;
+            float v = 0.0f;
+            if (k < kmax) {
+                const int cc = k / G::S, cell = k - cc * G::S, c = c0 + cc;
+                const float *pp = lds + G::HP_OFF + c * G::NTP + cell;
+                v = __builtin_fmaf((pp[0] + pp[8 * G::NTP]) + (pp[16 * G::NTP] + pp[24 * G::NTP]), kWUnscale, bh[c]);
+            }
+            const bool nz = v > 0.0f;
+            const unsigned long long m = __ballot(nz);
+            if (nz) {
+                const int at = n + __popcll(m & ((1ULL << lane) - 1ULL));
+                list[at].k = k;
+                list[at].x = v;
+            }
+            n += __popcll(m);
+        }
+        return n;
+    };
+    const int np = compact(4 * G::S, 0, lp);
+    const int nv = compact(2 * G::S, 4, lv);
+    if (lane == 0) { cnt[wave] = np; cnt[4 + wave] = nv; }
+    __syncthreads();
+    prof.mark(7);
+
+    // ---- act_fc1: this wave's inputs against all outputs, outputs 4*lane .. 4*lane+3 per lane
+    {
+        const gptr<f32x4> wrow = as_global(reinterpret_cast<const f32x4 *>(nw.wpfc_k)) + lane;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int i0 = 0; i0 < np; i0 += 16) {
+            f32x4 wv[16];
+            float xv[16];
+#pragma unroll
+            for (int u = 0; u < 16; u++) {
+                const Pair e = lp[i0 + u < np ? i0 + u : np - 1];            // clamp: keeps the load unconditional
+                xv[u] = i0 + u < np ? e.x : 0.0f;
+                wv[u] = wrow[(size_t)e.k * 64];
+            }
+#pragma unroll
+            for (int u = 0; u < 16; u++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) acc[j] = __builtin_fmaf(wv[u][j], xv[u], acc[j]);
+        }
+        *reinterpret_cast<f32x4 *>(lds + G::SPP_OFF + wave * 256 + 4 * lane) = acc;
+    }
+    // ---- val_fc1: lane group g = lane / 16 takes every fourth entry of the wave's list, a lane four outputs
+    {
+        const int grp = lane >> 4, l16 = lane & 15;
+        const gptr<f32x4> wrow = as_global(reinterpret_cast<const f32x4 *>(nw.wvfc1_k)) + l16;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int i0 = 0; i0 < nv; i0 += 4 * 8) {
+            f32x4 wv[8];
+            float xv[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int i = i0 + 4 * u + grp;
+                const Pair e = lv[i < nv ? i : nv - 1];
+                xv[u] = i < nv ? e.x : 0.0f;
+                wv[u] = wrow[(size_t)e.k * 16];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) acc[j] = __builtin_fmaf(wv[u][j], xv[u], acc[j]);
+        }
+        *reinterpret_cast<f32x4 *>(lds + G::SPV_OFF + (wave * 4 + grp) * 64 + 4 * l16) = acc;
+    }
+    __syncthreads();
+    prof.mark(8);
+
+    // ---- softmax over the S logits and the scalar value (wave 0; every partial is read before
+    //      the first result is written, the result slots overlap no partial)
+    if (wave == 0) {
+        float x[4];
+        float mx = -3.0e38f;
+        {
+            f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int w = 0; w < 4; w++) {
+                const f32x4 p = *reinterpret_cast<const f32x4 *>(lds + G::SPP_OFF + w * 256 + 4 * lane);
+#pragma unroll
+                for (int j = 0; j < 4; j++) s[j] += p[j];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int a = 4 * lane + j;
+                x[j] = a < G::S ? s[j] + lb[G::B_PFC + a] : -3.0e38f;
+                mx = fmaxf(mx, x[j]);
+            }
+        }
+        float hdn = lb[G::B_VFC1 + lane];
+#pragma unroll
+        for (int w = 0; w < 16; w++) hdn += lds[G::SPV_OFF + w * 64 + lane];
+        hdn = hdn > 0.0f ? hdn : 0.0f;
+        mx = wave_max_f32(mx);
+        float sum = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            if (4 * lane + j < G::S) sum += expf(x[j] - mx);
+        sum = wave_sum_f32(sum);
+        const float lse = logf(sum);
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            if (4 * lane + j < G::S) lds[G::LG_OFF + 4 * lane + j] = expf((x[j] - mx) - lse);
+        const float v = wave_sum_f32(hdn * lb[G::B_WVFC2 + lane]);
+        if (lane == 0) lds[G::VAL_OFF] = tanhf(v + lb[G::B_VFC2]);
+    }
+    __syncthreads();
+    prof.mark(9);
 }
 
 // Everything after conv3 for the split-f16 path: head outputs (bias + the four channel-tile
@@ -597,7 +738,8 @@ __device__ inline void cnn16_forward(const NetWeights &nw_in, float *lds, InputF
     __syncthreads();
     if (tid == 0) gate.release();
     prof.mark(6);
-    cnn16_tail<G>(nw, lds, tid, prof);
+    if constexpr (G::SPARSE_FC) cnn16_tail_sparse<G>(nw, lds, tid, prof);
+    else cnn16_tail<G>(nw, lds, tid, prof);
 }
 
 // One-time LDS set-up: the zero rows of the A2 images and the head weights.

@@ -34,6 +34,8 @@ struct NetWeights {
     const float *bvfc1;      // [64]
     const float *wvfc2;      // [64]
     const float *bvfc2;      // [1]
+    const float *wpfc_k;     // act_fc1 as [k][256]: one row of outputs per input feature (sparse-input FC)
+    const float *wvfc1_k;    // val_fc1 as [k][64]
 };
 
 // Returns p unchanged but opaque to the optimiser.  The CNN runs inside the playout loop and
@@ -62,6 +64,7 @@ __device__ inline NetWeights opaque_weights(const NetWeights &w)
     o.whead16 = opaque((const char *)w.whead16);
     o.whead = opaque(w.whead); o.bhead = opaque(w.bhead); o.wpfc = opaque(w.wpfc); o.bpfc = opaque(w.bpfc);
     o.wvfc1 = opaque(w.wvfc1); o.bvfc1 = opaque(w.bvfc1); o.wvfc2 = opaque(w.wvfc2); o.bvfc2 = opaque(w.bvfc2);
+    o.wpfc_k = opaque(w.wpfc_k); o.wvfc1_k = opaque(w.wvfc1_k);
     return o;
 }
 

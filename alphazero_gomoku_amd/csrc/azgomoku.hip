@@ -480,6 +480,9 @@ extern "C" int azg_set_weights(azg_handle *h, const float *const ptrs[16], int l
     total = offfc[1] + al((size_t)2 * ksv * 64 * 8);
     const size_t offh16 = total;
     total += 1024;                                           // 4 KB of head weights as halves
+    // row-per-input images of the two wide FC layers (sparse-input FC of the one-leaf kernels)
+    const size_t offpk = total, offvk = offpk + (size_t)4 * S * 256;
+    total = offvk + (size_t)2 * S * 64;
     if (h->cfg.cnn_mode == AZG_CNN_F16X3) {
         // halves hold w * 2^8: larger weights would overflow to infinity
         for (int i : {0, 2, 4, 6, 8, 10, 12})
@@ -510,6 +513,10 @@ extern "C" int azg_set_weights(azg_handle *h, const float *const ptrs[16], int l
     std::copy(t[9].begin(), t[9].end(), &host[off[9]]);
     for (int o = 0; o < 64; o++)
         for (int k = 0; k < 2 * S; k++) host[off[10] + ((size_t)(k / 4) * 64 + o) * 4 + k % 4] = t[12][(size_t)o * 2 * S + k];
+    for (int o = 0; o < S; o++)
+        for (int k = 0; k < 4 * S; k++) host[offpk + (size_t)k * 256 + o] = t[8][(size_t)o * 4 * S + k];
+    for (int o = 0; o < 64; o++)
+        for (int k = 0; k < 2 * S; k++) host[offvk + (size_t)k * 64 + o] = t[12][(size_t)o * 2 * S + k];
     std::copy(t[13].begin(), t[13].end(), &host[off[11]]);
     std::copy(t[14].begin(), t[14].end(), &host[off[12]]);
     host[off[13]] = t[15][0];
@@ -527,6 +534,7 @@ extern "C" int azg_set_weights(azg_handle *h, const float *const ptrs[16], int l
     nw.wpfc = d + off[8]; nw.bpfc = d + off[9];
     nw.wvfc1 = d + off[10]; nw.bvfc1 = d + off[11];
     nw.wvfc2 = d + off[12]; nw.bvfc2 = d + off[13];
+    nw.wpfc_k = d + offpk; nw.wvfc1_k = d + offvk;
     h->have_weights = true;
     return AZG_OK;
 }
