@@ -52,21 +52,24 @@ struct Cnn16Geom {
     static constexpr int B_HEAD = 224, B_VFC1 = 232, B_WVFC2 = 296, B_VFC2 = 360, B_PFC = 368;
     static constexpr int END_BYTES = BIAS_OFF + (B_PFC + ((S + 7) & ~7)) * 4;
     static constexpr int END = (END_BYTES + 3) / 4;           // in floats, like CnnGeom::END
-    // fully connected layers as MFMA GEMMs: D[output][leaf] = sum_k W[output][k] * x[k][leaf];
-    // every wave takes a quarter of the k-steps of every output tile
-    static constexpr int KWP = ((4 * S + 15) / 16 + 3) / 4;   // k-steps per wave, act_fc1
-    static constexpr int KWV = ((2 * S + 15) / 16 + 3) / 4;   // k-steps per wave, val_fc1
-    static constexpr int KPP = 4 * KWP * 16, KPV = 4 * KWV * 16;   // padded input lengths
-    static constexpr int OTP = (S + 31) / 32;                 // output tiles of act_fc1 (val_fc1 has 2)
-    static constexpr int OC = OTP < 4 ? OTP : 4;              // output tiles per accumulator group
-    static constexpr int NOUT = OTP * 32 + 64;
+    // fully connected layers as MFMA GEMMs on v_mfma_f32_16x16x32_f16: D[leaf][output] =
+    // sum_k x[leaf][k] * W[output][k], 16 leaf rows (T in use), 16 outputs and 32 inputs per
+    // instruction; every wave takes a quarter of the k-steps of every output tile
+    static constexpr int KWP = ((4 * S + 31) / 32 + 3) / 4;   // k-steps per wave, act_fc1
+    static constexpr int KWV = ((2 * S + 31) / 32 + 3) / 4;   // k-steps per wave, val_fc1
+    static constexpr int KPP = 4 * KWP * 32, KPV = 4 * KWV * 32;   // padded input lengths
+    static constexpr int OTP = (S + 15) / 16;                 // output tiles of act_fc1 (val_fc1 has 4)
+    static constexpr int OC = OTP % 4 == 0 ? 4 : OTP % 3 == 0 ? 3 : OTP % 2 == 0 ? 2 : 1;   // output tiles per accumulator group
+    static constexpr int NOUT = OTP * 16 + 64;
     static_assert(OTP % OC == 0, "act_fc1 output tiles must split evenly into accumulator groups");
     // f32 scratch that aliases IN + A1 once conv2 has consumed them (float offsets)
     static constexpr int HP_OFF = 0;                          // head partials [4 waves][8][NTP] (rows 6, 7 unused)
     static constexpr int PART_OFF = 0;                        // FC partials [4 waves][NOUT][T] (HP is dead by then)
     static constexpr int LG_OFF = PART_OFF + 4 * NOUT * T_;   // probabilities [T][S]
     static constexpr int VAL_OFF = LG_OFF + T_ * S;           // values [T]
-    static constexpr int X_OFF = HP_OFF + 32 * NTP;           // head outputs as halves: hi [T][KPP], lo [T][KPP], hi [T][KPV], lo [T][KPV]
+    // head outputs as halves: hi [T][KPP], lo [T][KPP], hi [T][KPV], lo [T][KPV]; they start on the last
+    // wave's rows 6 and 7 of the head partials, which are written (zeros) before but never read
+    static constexpr int X_OFF = HP_OFF + 30 * NTP;
     static constexpr int X_END = X_OFF + T_ * (KPP + KPV);
     // One-leaf kernels (T == 1): the fully connected layers run on the VALU over the NON-ZERO head
     // outputs only.  Wave w owns the inputs k = 4*i + w; its (k, x) pairs sit in lists behind the
@@ -258,7 +261,7 @@ __device__ inline float wave_sum_f32(float v)
 #ifndef AZG_FC_RING
 #define AZG_FC_RING 28        // weight units (k-step, tile) of a fully connected layer in flight per wave
 #endif
-// One group of 32-output tiles of a fully connected layer for one wave: NTG tiles, the wave's
+// One group of 16-output tiles of a fully connected layer for one wave: NTG tiles, the wave's
 // KW k-steps of each.  Units (k-step, tile) stream through a ring of RU register pairs.
 template <int NTG, int KW>
 struct FcRing {
@@ -286,24 +289,26 @@ __device__ inline void fc16_preload(gptr<half8> w, int ks_total, FcRing<NTG, KW>
     __builtin_amdgcn_sched_barrier(0);
 }
 
-// x is the A operand (row = leaf) and W the B operand (column = output), so a lane of the lower
-// half-wave ends up with one output's value for every leaf in accumulator registers 0 .. T-1.
+// x is the A operand (row = leaf) and W the B operand (column = output): lane l supplies the
+// eight inputs 8*(l/16) .. +7 of leaf row / output column l%16, and lanes 0..15 end up with one
+// output's value for leaf t in accumulator register t.
 // xi: this lane's 16 bytes of the hi image at the wave's first k-step; lo image xlo_off further.
 template <int T, int NTG, int KW>
 __device__ inline void fc16_run(gptr<half8> w, int ks_total, FcRing<NTG, KW> &r, const char *xi, int xlo_off,
-                                bool leaf_lane, float *out /* + (first output of the group) * T */, int half, int n)
+                                bool leaf_lane, float *out /* + (first output of the group) * T */, int kgrp, int n)
 {
     using R = FcRing<NTG, KW>;
+    static_assert(T <= 4, "leaf t is read from accumulator register t of the first lane group");
     const half8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
-    const f32x16 zacc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    f32x16 acc[NTG];
+    const f32x4 zacc = {0.f, 0.f, 0.f, 0.f};
+    f32x4 acc[NTG];
     half8 xh = z8, xl = z8;
 #pragma unroll
     for (int u = 0; u < R::NU; u++) {
         const int kk = u / NTG, i = u - kk * NTG;
         if (i == 0) {
-            xh = *reinterpret_cast<const half8 *>(xi + kk * 32);
-            xl = *reinterpret_cast<const half8 *>(xi + kk * 32 + xlo_off);
+            xh = *reinterpret_cast<const half8 *>(xi + kk * 64);
+            xl = *reinterpret_cast<const half8 *>(xi + kk * 64 + xlo_off);
             if (!leaf_lane) { xh = z8; xl = z8; }
         }
         const half8 wa = r.ah[u % R::RU], wl = r.al[u % R::RU];
@@ -311,15 +316,15 @@ __device__ inline void fc16_run(gptr<half8> w, int ks_total, FcRing<NTG, KW> &r,
             const gptr<half8> s = fc16_src<NTG, KW>(w, ks_total, u + R::RU);
             r.ah[u % R::RU] = s[0]; r.al[u % R::RU] = s[1];
         }
-        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, wa, kk == 0 ? zacc : acc[i], 0, 0, 0);
-        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, wl, acc[i], 0, 0, 0);
-        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xl, wa, acc[i], 0, 0, 0);
+        acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh, wa, kk == 0 ? zacc : acc[i], 0, 0, 0);
+        acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh, wl, acc[i], 0, 0, 0);
+        acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xl, wa, acc[i], 0, 0, 0);
     }
-    if (half == 0) {
+    if (kgrp == 0) {
 #pragma unroll
         for (int i = 0; i < NTG; i++)
 #pragma unroll
-            for (int t = 0; t < T; t++) out[(i * 32 + n) * T + t] = acc[i][t];
+            for (int t = 0; t < T; t++) out[(i * 16 + n) * T + t] = acc[i][t];
     }
 }
 
@@ -456,7 +461,7 @@ __device__ inline void cnn16_tail_sparse(const NetWeights &nw, float *lds, int t
 
 // Everything after conv3 for the split-f16 path: head outputs (bias + the four channel-tile
 // partials, ReLU) written as half pairs, both fully connected layers on the matrix cores,
-// softmax and tanh.  A wave takes k-steps [wave*KW, (wave+1)*KW) of every 32-output tile; the
+// softmax and tanh.  A wave takes k-steps [wave*KW, (wave+1)*KW) of every 16-output tile; the
 // four partial sums per output meet in LDS and are added in a fixed order.  The first weights
 // of both layers are requested before the head outputs are formed, so the L2 latency of the
 // weight stream overlaps that stage.
@@ -465,14 +470,14 @@ __device__ inline void cnn16_tail(const NetWeights &nw, float *lds, int tid, Pro
 {
     char *ldb = reinterpret_cast<char *>(lds);
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    const int half = lane >> 5, n = lane & 31;
+    const int kgrp = lane >> 4, n = lane & 15;             // FC operand geometry: k group and row / column of the lane
     constexpr int NGP = G::OTP / G::OC;                    // accumulator groups of act_fc1
     const gptr<half8> wpol = as_global(reinterpret_cast<const half8 *>(nw.wfc16[0])) + ((size_t)wave * G::KWP * 64 + lane) * 2;
     const gptr<half8> wval = as_global(reinterpret_cast<const half8 *>(nw.wfc16[1])) + ((size_t)wave * G::KWV * 64 + lane) * 2;
     FcRing<G::OC, G::KWP> rpol;
-    FcRing<2, G::KWV> rval;
+    FcRing<4, G::KWV> rval;
     fc16_preload<G::OC, G::KWP>(wpol, 4 * G::KWP, rpol);
-    fc16_preload<2, G::KWV>(wval, 4 * G::KWV, rval);
+    fc16_preload<4, G::KWV>(wval, 4 * G::KWV, rval);
 
     // ---- head outputs, flattened [c][row][col] per head like the reference's view(-1, ...)
     {
@@ -534,18 +539,18 @@ __device__ inline void cnn16_tail(const NetWeights &nw, float *lds, int tid, Pro
     // ---- act_fc1 and val_fc1
     {
         const int leafc = n < G::T ? n : 0;
-        const char *xp = ldb + G::X_OFF * 4 + (leafc * G::KPP + wave * G::KWP * 16 + 8 * half) * 2;
-        const char *xv = ldb + G::X_OFF * 4 + 2 * G::T * G::KPP * 2 + (leafc * G::KPV + wave * G::KWV * 16 + 8 * half) * 2;
+        const char *xp = ldb + G::X_OFF * 4 + (leafc * G::KPP + wave * G::KWP * 32 + 8 * kgrp) * 2;
+        const char *xv = ldb + G::X_OFF * 4 + 2 * G::T * G::KPP * 2 + (leafc * G::KPV + wave * G::KWV * 32 + 8 * kgrp) * 2;
         float *part = lds + G::PART_OFF + wave * G::NOUT * G::T;
-        fc16_run<G::T, G::OC, G::KWP>(wpol, 4 * G::KWP, rpol, xp, G::T * G::KPP * 2, n < G::T, part, half, n);
+        fc16_run<G::T, G::OC, G::KWP>(wpol, 4 * G::KWP, rpol, xp, G::T * G::KPP * 2, n < G::T, part, kgrp, n);
         for (int grp = 1; grp < NGP; grp++) {
             const gptr<half8> wg = wpol + (size_t)grp * G::OC * (4 * G::KWP) * 128;
             fc16_preload<G::OC, G::KWP>(wg, 4 * G::KWP, rpol);
             fc16_run<G::T, G::OC, G::KWP>(wg, 4 * G::KWP, rpol, xp, G::T * G::KPP * 2, n < G::T,
-                                          part + grp * G::OC * 32 * G::T, half, n);
+                                          part + grp * G::OC * 16 * G::T, kgrp, n);
         }
-        fc16_run<G::T, 2, G::KWV>(wval, 4 * G::KWV, rval, xv, G::T * G::KPV * 2, n < G::T,
-                                  part + G::OTP * 32 * G::T, half, n);
+        fc16_run<G::T, 4, G::KWV>(wval, 4 * G::KWV, rval, xv, G::T * G::KPV * 2, n < G::T,
+                                  part + G::OTP * 16 * G::T, kgrp, n);
     }
     __syncthreads();
     prof.mark(8);
@@ -582,7 +587,7 @@ __device__ inline void cnn16_tail(const NetWeights &nw, float *lds, int tid, Pro
             const int a = lane + 64 * i;
             if (a < G::S) lds[G::LG_OFF + leaf * G::S + a] = expf((x[i] - mx) - lse);
         }
-        float hdn = fc_out(G::OTP * 32 + lane, lb[G::B_VFC1 + lane]);
+        float hdn = fc_out(G::OTP * 16 + lane, lb[G::B_VFC1 + lane]);
         hdn = hdn > 0.0f ? hdn : 0.0f;
         float v = hdn * lb[G::B_WVFC2 + lane];
         v = wave_sum_f32(v);

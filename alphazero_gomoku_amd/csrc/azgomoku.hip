@@ -391,18 +391,19 @@ static void pack_conv16(const float *w, int cin, int cinp, int cout, _Float16 *o
             }
 }
 
-// Split-f16 image of a fully connected matrix W[O][K] (row-major) for azg_cnn16.hpp: per
-// (output tile of 32, k-step of 16) and lane, 8 high halves then 8 low halves of
-// W[o = tile*32 + (lane&31)][k = ks*16 + 8*(lane>>5) + j] * 2^8; rows >= O and columns >= K are zero.
+// Split-f16 image of a fully connected matrix W[O][K] (row-major) for azg_cnn16.hpp
+// (v_mfma_f32_16x16x32_f16 B operand): per (output tile of 16, k-step of 32) and lane, 8 high
+// halves then 8 low halves of W[o = tile*16 + (lane&15)][k = ks*32 + 8*(lane>>4) + j] * 2^8; rows >= O
+// and columns >= K are zero.
 static void pack_fc16(const float *w, int O, int K, int otiles, int ksteps, _Float16 *out)
 {
     for (int ot = 0; ot < otiles; ot++)
         for (int ks = 0; ks < ksteps; ks++)
             for (int lane = 0; lane < 64; lane++) {
-                const int o = ot * 32 + (lane & 31);
+                const int o = ot * 16 + (lane & 15);
                 _Float16 *dst = out + (((size_t)ot * ksteps + ks) * 64 + lane) * 16;
                 for (int j = 0; j < 8; j++) {
-                    const int k = ks * 16 + 8 * (lane >> 5) + j;
+                    const int k = ks * 32 + 8 * (lane >> 4) + j;
                     const float v = (o < O && k < K) ? w[(size_t)o * K + k] * kWScale : 0.0f;
                     const _Float16 hi = (_Float16)v;
                     dst[j] = hi;
@@ -475,9 +476,9 @@ extern "C" int azg_set_weights(azg_handle *h, const float *const ptrs[16], int l
     const size_t psz16[3] = {(size_t)1 * 9 * 64 * 8, (size_t)2 * 18 * 64 * 8, (size_t)4 * 36 * 64 * 8};
     for (int i = 0; i < 3; i++) { off16[i] = total; total += al(psz16[i]); }
     // split-f16 FC images: k-steps padded to a multiple of 4 (one quarter per wave)
-    const int otp = (S + 31) / 32, ksp = ((4 * S + 15) / 16 + 3) / 4 * 4, ksv = ((2 * S + 15) / 16 + 3) / 4 * 4;
+    const int otp = (S + 15) / 16, ksp = ((4 * S + 31) / 32 + 3) / 4 * 4, ksv = ((2 * S + 31) / 32 + 3) / 4 * 4;
     const size_t offfc[2] = {total, total + al((size_t)otp * ksp * 64 * 8)};
-    total = offfc[1] + al((size_t)2 * ksv * 64 * 8);
+    total = offfc[1] + al((size_t)4 * ksv * 64 * 8);
     const size_t offh16 = total;
     total += 1024;                                           // 4 KB of head weights as halves
     // row-per-input images of the two wide FC layers (sparse-input FC of the one-leaf kernels)
@@ -499,7 +500,7 @@ extern "C" int azg_set_weights(azg_handle *h, const float *const ptrs[16], int l
     pack_conv16(t[2].data(), 32, 32, 64, reinterpret_cast<_Float16 *>(&host[off16[1]]));
     pack_conv16(t[4].data(), 64, 64, 128, reinterpret_cast<_Float16 *>(&host[off16[2]]));
     pack_fc16(t[8].data(), S, 4 * S, otp, ksp, reinterpret_cast<_Float16 *>(&host[offfc[0]]));
-    pack_fc16(t[12].data(), 64, 2 * S, 2, ksv, reinterpret_cast<_Float16 *>(&host[offfc[1]]));
+    pack_fc16(t[12].data(), 64, 2 * S, 4, ksv, reinterpret_cast<_Float16 *>(&host[offfc[1]]));
     std::copy(t[1].begin(), t[1].end(), &host[off[3]]);
     std::copy(t[3].begin(), t[3].end(), &host[off[4]]);
     std::copy(t[5].begin(), t[5].end(), &host[off[5]]);
