@@ -258,6 +258,79 @@ __device__ inline float wave_sum_f32(float v)
     return (lane_f32(v, 0) + lane_f32(v, 16)) + (lane_f32(v, 32) + lane_f32(v, 48));
 }
 
+// conv1 (4 input planes, exact 0/1 values): the 36 products per output are packed as
+// k = tap*4 + plane into three k-steps of 16 (a lane's eight k-values are two taps of four planes,
+// two 8-byte LDS reads) instead of nine k-steps that carry 4 real channels in 16.  No w_hi*x_lo
+// term.  wp: per k-step and lane 8 hi then 8 lo halves of W[co = lane&31][plane = j%4][tap =
+// 4*ks + 2*(lane>>5) + j/4] * 2^8 (zero for tap >= 9).  ring: all three k-steps, preloaded.
+__device__ inline void conv1_preload(const half8 *wp, int lane, WRing<3> &r)
+{
+    const gptr<half8> wrow = as_global(wp + (size_t)lane * 2);
+#pragma unroll
+    for (int d = 0; d < 3; d++) { r.ah[d] = wrow[(size_t)d * 128]; r.al[d] = wrow[(size_t)d * 128 + 1]; }
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+template <class G, class Prep, class Epi>
+__device__ inline void conv1_packed_f16(WRing<3> &ring, const char *xin, int wave, int lane, Prep prep, Epi epi, Prof *prof, int slot)
+{
+    constexpr int RS = G::RS_IN;
+    constexpr int PT = (G::NT + 3) / 4;
+    const int half = lane >> 5, j = lane & 31;
+    const int zero = G::NP * RS;
+    int base[PT], prow[PT];
+    unsigned vmask[PT];
+#pragma unroll
+    for (int i = 0; i < PT; i++) {
+        const int tile = wave * PT + i;
+        const int p = tile * 32 + j;
+        base[i] = zero; vmask[i] = 0; prow[i] = -1;
+        if (tile < G::NT && p < G::NP) {
+            const int leaf = p / G::S, cell = p - leaf * G::S;
+            const int row = cell / G::N, col = cell - row * G::N;
+            base[i] = p * RS;
+            prow[i] = p;
+            unsigned m = 0x1FFu;
+            if (row == 0) m &= ~0x007u;
+            if (row == G::N - 1) m &= ~0x1C0u;
+            if (col == 0) m &= ~0x049u;
+            if (col == G::N - 1) m &= ~0x124u;
+            vmask[i] = m;
+        }
+    }
+    if (prof) prof->mark(slot - 1);
+    const f32x16 zacc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    f32x16 acc[PT];
+    half8 b[3][PT];
+#pragma unroll
+    for (int ks = 0; ks < 3; ks++)
+#pragma unroll
+        for (int i = 0; i < PT; i++) {
+            half4 t2[2];
+#pragma unroll
+            for (int e = 0; e < 2; e++) {
+                const int tap = 4 * ks + 2 * half + e;                  // per-lane (two values: half = 0 / 1)
+                const int dr = tap / 3 - 1, dc = tap - (tap / 3) * 3 - 1;
+                const bool on = tap < 9 && ((vmask[i] >> tap) & 1u);
+                const int a = on ? base[i] + (dr * G::N + dc) * RS : zero;
+                t2[e] = *reinterpret_cast<const half4 *>(xin + a);
+            }
+            b[ks][i] = __builtin_shufflevector(t2[0], t2[1], 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+#pragma unroll
+    for (int ks = 0; ks < 3; ks++)
+#pragma unroll
+        for (int i = 0; i < PT; i++) {
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring.ah[ks], b[ks][i], ks == 0 ? zacc : acc[i], 0, 0, 0);
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring.al[ks], b[ks][i], acc[i], 0, 0, 0);
+        }
+    if (prof) prof->mark(slot);
+    const auto ctx = prep();
+#pragma unroll
+    for (int i = 0; i < PT; i++)
+        if (wave * PT + i < G::NT) epi(i, wave * PT + i, acc[i], prow[i], ctx);
+}
+
 #ifndef AZG_FC_RING
 #define AZG_FC_RING 28        // weight units (k-step, tile) of a fully connected layer in flight per wave
 #endif
@@ -615,14 +688,14 @@ __device__ inline void cnn16_forward(const NetWeights &nw_in, float *lds, InputF
     const half8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
 
     const float *lbias = lds + G::BIAS_OFF / 4;            // conv1 | conv2 | conv3 | head biases
-    constexpr int R1 = 9, R2 = 6, R3 = 3;                 // k-steps of weights in flight per layer
+    constexpr int R2 = 6, R3 = 3;                         // k-steps of weights in flight per layer (conv1: all three)
     const half8 *w1 = reinterpret_cast<const half8 *>(nw.w16[0]);
     const half8 *w2 = reinterpret_cast<const half8 *>(nw.w16[1]);
     const half8 *w3 = reinterpret_cast<const half8 *>(nw.w16[2]);
-    WRing<R1> ring1;
+    WRing<3> ring1;
     WRing<R2> ring2;
     WRing<R3> ring3;
-    conv_preload<16, 32, R1>(w1, wave, lane, ring1);
+    conv1_preload(w1, lane, ring1);
 
     // ---- input image: the 4 planes as halves in channels 0..3 of a 16-channel row; the
     //      zero rows of the IN and A1 images are rewritten (the f32 scratch overlaps them)
@@ -676,8 +749,8 @@ __device__ inline void cnn16_forward(const NetWeights &nw_in, float *lds, InputF
         };
     };
     conv_preload<32, 64, R2>(w2, wave, lane, ring2);
-    conv3x3_f16<G, 16, 32, G::RS_IN, false, G::BPF, R1>(w1, ring1, ldb + G::IN_OFF, ldb + G::IN_OFF, wave, lane,
-                                                load_bias(lbias, 0), store_split(0, ldb + G::A1H_OFF, ldb + G::A1L_OFF, G::RS_A1), &prof, 13);
+    conv1_packed_f16<G>(ring1, ldb + G::IN_OFF, wave, lane,
+                        load_bias(lbias, 0), store_split(0, ldb + G::A1H_OFF, ldb + G::A1L_OFF, G::RS_A1), &prof, 13);
     prof.mark(16);
     if (tid == 0) gate.acquire();
     __syncthreads();

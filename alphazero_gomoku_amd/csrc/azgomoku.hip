@@ -391,6 +391,25 @@ static void pack_conv16(const float *w, int cin, int cinp, int cout, _Float16 *o
             }
 }
 
+// Split-f16 image of conv1 for azg_cnn16.hpp's conv1_packed_f16: k = tap*4 + plane in three k-steps
+// of 16; per k-step and lane 8 high then 8 low halves of W[co = lane&31][plane = j%4][tap = 4*ks +
+// 2*(lane>>5) + j/4] * 2^8, zero for tap >= 9.
+static void pack_conv1_16(const float *w /*[32][4][3][3]*/, _Float16 *out)
+{
+    for (int ks = 0; ks < 3; ks++)
+        for (int lane = 0; lane < 64; lane++) {
+            const int co = lane & 31;
+            _Float16 *dst = out + ((size_t)ks * 64 + lane) * 16;
+            for (int j = 0; j < 8; j++) {
+                const int tap = 4 * ks + 2 * (lane >> 5) + j / 4, ci = j % 4;
+                const float v = tap < 9 ? w[((size_t)co * 4 + ci) * 9 + tap] * kWScale : 0.0f;
+                const _Float16 hi = (_Float16)v;
+                dst[j] = hi;
+                dst[8 + j] = (_Float16)(v - (float)hi);
+            }
+        }
+}
+
 // Split-f16 image of a fully connected matrix W[O][K] (row-major) for azg_cnn16.hpp
 // (v_mfma_f32_16x16x32_f16 B operand): per (output tile of 16, k-step of 32) and lane, 8 high
 // halves then 8 low halves of W[o = tile*16 + (lane&15)][k = ks*32 + 8*(lane>>4) + j] * 2^8; rows >= O
@@ -473,7 +492,7 @@ extern "C" int azg_set_weights(azg_handle *h, const float *const ptrs[16], int l
                             6 * 128, 6, (size_t)4 * S * S, (size_t)S, (size_t)((2 * S + 3) / 4) * 64 * 4, 64, 64, 1};
     for (int i = 0; i < 14; i++) { off[i] = total; total += al(psz[i]); }
     // split-f16 conv images: (cotiles * 9*CG k-steps * 64 lanes * 16 halves) / 2 floats
-    const size_t psz16[3] = {(size_t)1 * 9 * 64 * 8, (size_t)2 * 18 * 64 * 8, (size_t)4 * 36 * 64 * 8};
+    const size_t psz16[3] = {(size_t)3 * 64 * 8, (size_t)2 * 18 * 64 * 8, (size_t)4 * 36 * 64 * 8};
     for (int i = 0; i < 3; i++) { off16[i] = total; total += al(psz16[i]); }
     // split-f16 FC images: k-steps padded to a multiple of 4 (one quarter per wave)
     const int otp = (S + 15) / 16, ksp = ((4 * S + 31) / 32 + 3) / 4 * 4, ksv = ((2 * S + 31) / 32 + 3) / 4 * 4;
@@ -496,7 +515,7 @@ extern "C" int azg_set_weights(azg_handle *h, const float *const ptrs[16], int l
     pack_conv(t[0].data(), 4, 32, &host[off[0]]);
     pack_conv(t[2].data(), 32, 64, &host[off[1]]);
     pack_conv(t[4].data(), 64, 128, &host[off[2]]);
-    pack_conv16(t[0].data(), 4, 16, 32, reinterpret_cast<_Float16 *>(&host[off16[0]]));
+    pack_conv1_16(t[0].data(), reinterpret_cast<_Float16 *>(&host[off16[0]]));
     pack_conv16(t[2].data(), 32, 32, 64, reinterpret_cast<_Float16 *>(&host[off16[1]]));
     pack_conv16(t[4].data(), 64, 64, 128, reinterpret_cast<_Float16 *>(&host[off16[2]]));
     pack_fc16(t[8].data(), S, 4 * S, otp, ksp, reinterpret_cast<_Float16 *>(&host[offfc[0]]));
