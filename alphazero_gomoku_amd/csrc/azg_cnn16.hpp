@@ -770,19 +770,20 @@ __device__ inline void cnn16_forward(const NetWeights &nw_in, float *lds, InputF
     //      the head weights are packed to match).  The four waves' partial sums meet in LDS.
     {
         const float *b3 = lbias + 96 + wave * 32;
-        struct Head16 { f32x4 b[4]; half8 wh[2], wl[2]; };
+        // The head tile has 32 rows and 6 head channels: rows 0-7 carry the high halves of the
+        // head weights and rows 8-15 the low halves, so ONE instruction per activation half
+        // forms both w_hi*x and w_lo*x; adding the two row blocks afterwards gives the full
+        // (w_hi + w_lo)(x_hi + x_lo) with two MFMAs per k-step instead of three.
+        struct Head16 { f32x4 b[4]; half8 w[2]; };
         float *hp = lds + G::HP_OFF + wave * 8 * G::NTP;
-        const char *whp = ldb + G::WH_OFF + ((wave * 4 + half) * 8 + (j < 8 ? j : 7)) * 32;
+        const char *whp = ldb + G::WH_OFF + ((wave * 4 + half) * 8 + (j < 16 ? (j & 7) : 7)) * 32 + ((j >= 8 && j < 16) ? 16 : 0);
         conv3x3_f16<G, 64, 128, G::RS_A2, true, G::BPF, R3>(w3, ring3, ldb + G::A2H_OFF, ldb + G::A2L_OFF, wave, lane,
             [=]() {
                 Head16 c;
 #pragma unroll
                 for (int g = 0; g < 4; g++) c.b[g] = *reinterpret_cast<const f32x4 *>(b3 + 8 * g + 4 * half);
 #pragma unroll
-                for (int s2 = 0; s2 < 2; s2++) {
-                    c.wh[s2] = *reinterpret_cast<const half8 *>(whp + s2 * 512);
-                    c.wl[s2] = *reinterpret_cast<const half8 *>(whp + s2 * 512 + 16);
-                }
+                for (int s2 = 0; s2 < 2; s2++) c.w[s2] = *reinterpret_cast<const half8 *>(whp + s2 * 512);
                 return c;
             },
             [=](int, int tile, const f32x16 &acc, int p, const Head16 &c) {
@@ -800,16 +801,16 @@ __device__ inline void cnn16_forward(const NetWeights &nw_in, float *lds, InputF
                         xh8[e] = hh;
                         xl8[e] = (_Float16)(v - (float)hh);
                     }
-                    hd = __builtin_amdgcn_mfma_f32_32x32x16_f16(c.wh[s2], xh8, hd, 0, 0, 0);
-                    hd = __builtin_amdgcn_mfma_f32_32x32x16_f16(c.wl[s2], xh8, hd, 0, 0, 0);
-                    hd = __builtin_amdgcn_mfma_f32_32x32x16_f16(c.wh[s2], xl8, hd, 0, 0, 0);
+                    hd = __builtin_amdgcn_mfma_f32_32x32x16_f16(c.w[s2], xh8, hd, 0, 0, 0);
+                    hd = __builtin_amdgcn_mfma_f32_32x32x16_f16(c.w[s2], xl8, hd, 0, 0, 0);
                 }
                 // rows 0-3 of the head tile sit in registers 0-3 of lanes 0-31, rows 4-7 in
-                // registers 0-3 of lanes 32-63 (rows 6, 7 are zero: their weights are)
+                // registers 0-3 of lanes 32-63 (rows 6, 7 are zero: their weights are); the
+                // low-half rows 8-15 sit in registers 4-7 of the same lanes
                 if (G::NP != G::NTP && p < 0) return;       // padding lane of the last tile
                 float *dst = hp + (4 * half) * G::NTP + tile * 32 + j;
 #pragma unroll
-                for (int c = 0; c < 4; c++) dst[c * G::NTP] = hd[c];
+                for (int c = 0; c < 4; c++) dst[c * G::NTP] = hd[c] + hd[4 + c];
             }, &prof);
     }
     prof.mark(5);
