@@ -51,7 +51,7 @@ __device__ inline void net_prepare(const NetWeights &nw, float *smem)
 #define AZG_GATE8 1     // per-CU matrix gate for those kernels
 #endif
 template <int N, int T, int MODE, bool F16>
-__global__ __launch_bounds__(256, (F16 && MODE == 0 && N <= 8) ? AZG_OCC8 : 1) void search_kernel(DevState st)
+__device__ __forceinline__ void search_body(DevState st)
 {
     using G = typename GeomPick<(MODE == 0 ? N : 4), (MODE == 0 ? T : 1), F16>::type;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -158,6 +158,31 @@ __global__ __launch_bounds__(256, (F16 && MODE == 0 && N <= 8) ? AZG_OCC8 : 1) v
     prof.finish();
     if (active && lane == 0) { st.evals[g] += n_eval; st.used[g] = gl->used; }
 }
+
+template <int N, int T, int MODE, bool F16>
+__global__ __launch_bounds__(256, (F16 && MODE == 0 && N <= 8) ? AZG_OCC8 : 1) void search_kernel(DevState st)
+{
+    search_body<N, T, MODE, F16>(st);
+}
+
+// Entry points of the split-f16 kernels that run two workgroups per CU, capped at 240 registers:
+// two waves per SIMD then leave 32 of the 512 registers free, which a wave of the runtime's copy
+// kernel needs to run BESIDE the search (the noise upload of the pipelined move step); at 248 the
+// copies wait for the whole search launch and a move step grows by 0.3 ms.  On gfx950 (unified
+// register file) amdgpu_num_vgpr counts half of what it limits: 120 caps the kernel at 240.  The
+// attribute takes no template-dependent argument, hence plain kernels around the common body.
+#if AZG_OCC8 == 2
+#ifndef AZG_VGPR_ATTR
+#define AZG_VGPR_ATTR 120
+#endif
+#define AZG_CAPPED_SEARCH_KERNEL(NAME, N, T)                                                                      \
+    __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(AZG_VGPR_ATTR))) void NAME(DevState st) \
+    {                                                                                                             \
+        search_body<N, T, 0, true>(st);                                                                           \
+    }
+AZG_CAPPED_SEARCH_KERNEL(search_kernel_f16_6x6, 6, 2)
+AZG_CAPPED_SEARCH_KERNEL(search_kernel_f16_8x8, 8, 2)
+#endif
 
 // ---------------------------------------------------------------- eval_batch
 // PolicyValueNet.policy_value (policy_value_net_pytorch.py:80-94) on n states.

@@ -136,11 +136,17 @@ static bool pick_search(int N, int mode, int cnn_mode, SearchLaunch *out)
     if (mode == AZG_PRIOR_HASH) { *out = {search_kernel<0, 4, 2, false>, 4, 4 * sizeof(GameLds)}; return true; }
     const bool f16 = cnn_mode == AZG_CNN_F16X3;
     switch (N) {
-    case 6: *out = f16 ? net_launch<6, 2, true>() : net_launch<6, 2, false>(); return true;
-    case 8: *out = f16 ? net_launch<8, AZG_T8, true>() : net_launch<8, 2, false>(); return true;
-    case 15: *out = f16 ? net_launch<15, 1, true>() : net_launch<15, 1, false>(); return true;
+    case 6: *out = f16 ? net_launch<6, 2, true>() : net_launch<6, 2, false>(); break;
+    case 8: *out = f16 ? net_launch<8, AZG_T8, true>() : net_launch<8, 2, false>(); break;
+    case 15: *out = f16 ? net_launch<15, 1, true>() : net_launch<15, 1, false>(); break;
     default: return false;
     }
+#if AZG_OCC8 == 2 && AZG_T8 == 2
+    // same code, register-capped entry points (see AZG_CAPPED_SEARCH_KERNEL)
+    if (f16 && N == 6) out->fn = search_kernel_f16_6x6;
+    if (f16 && N == 8) out->fn = search_kernel_f16_8x8;
+#endif
+    return true;
 }
 
 struct EvalLaunch {

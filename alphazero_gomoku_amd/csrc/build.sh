@@ -17,11 +17,10 @@ hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared -std=c++17 -Wall
 if grep -q "warning:" "$log"; then
     awk '/kernel-resource-usage/ { skip = 2; next } skip > 0 { skip--; next } { print }' "$log" >&2
 fi
-# The split-f16 search kernels for boards up to 8x8 run two workgroups per CU.  Up to 240 VGPRs,
-# two waves per SIMD leave 32 of the 512 registers free, which a wave of the runtime's copy kernel
-# needs to run BESIDE the search (the noise upload of the pipelined move step); at 248 the copy
-# waits for the whole search launch and a move step grows by 0.3 ms (measured).
-awk '/Function Name: _ZN3azg13search_kernelILi[68]ELi2ELi0ELb1EEEvNS_8DevStateE/ { k = $0; sub(/.*Function Name: /, "", k); sub(/ .*/, "", k) }
+# The split-f16 search kernels for boards up to 8x8 run two workgroups per CU and are capped at 240
+# VGPRs (azg_kernels.hpp, AZG_CAPPED_SEARCH_KERNEL), so that copy kernels can run beside them;
+# this check reports a build in which the cap did not hold.
+awk '/Function Name: _ZN3azg21search_kernel_f16_[68]x[68]ENS_8DevStateE/ { k = $0; sub(/.*Function Name: /, "", k); sub(/ .*/, "", k) }
      k != "" && / VGPRs: / { v = $0; sub(/.* VGPRs: /, "", v); sub(/ .*/, "", v);
          if (v + 0 > 240) printf("WARNING: %s uses %d VGPRs (> 240): copy kernels cannot run beside it\n", k, v);
          k = "" }' "$log" >&2
