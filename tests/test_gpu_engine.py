@@ -741,3 +741,48 @@ def test_weight_files_in_both_layouts(az, oracle, tmp_path):
     probs, vals = eng.eval_batch(st.astype(np.float32))
     assert np.abs(probs[0] - po).max() < 1e-5
     eng.close()
+
+
+def test_full_batch_pipelined_games_equal_oracle_games_with_gpu_priors(az, oracle):
+    """Configuration C2 as the benchmark runs it (1024 slots, 8x8 / 5-in-row / 400 playouts, CNN leaf
+    evaluation, pipelined device refill): whole games taken from the first cohort must equal, tuple
+    for tuple, the oracle's self-play game for the same seed when the oracle's tree is fed the GPU
+    CNN's own float32 outputs (pi to 1e-12, states and z exactly)."""
+    n, k, npo, B, seed0 = 8, 5, 400, 1024, 4000
+    params = helpers.make_params(n, seed=108)
+    eng = az.SelfPlayEngine(n, k, npo, B, 5.0)
+    eng.set_weights(params)
+    ev = az.SelfPlayEngine(n, k, 1, 1)
+    ev.set_weights(params)
+    want = (3, 517, 1023)
+    got = {}
+
+    def sink(s):
+        for gid in want:
+            sel = np.nonzero(s["game_id"] == gid)[0]
+            if len(sel):
+                got[gid] = {key: s[key][sel[np.argsort(s["ply"][sel])]] for key in s}
+    from alphazero_gomoku_amd.engine import SelfPlayRunner
+    run = SelfPlayRunner(eng, temp=1.0, seed0=seed0, total=None, on_samples=sink, pipelined=True)
+    run.start()
+    for _ in range(70):
+        run.step()
+        if len(got) == len(want):
+            break
+    run.finish()
+    assert len(got) == len(want), "the chosen games did not finish within 70 move steps"
+
+    def policy(b):
+        ob = oracle.OracleBoard(n, n, k)
+        ob.b = b
+        pr, v = ev.eval_batch(ob.current_state().astype(np.float32))
+        return [float(x) for x in pr[0]], float(v[0])
+    for gid in want:
+        r = oracle.self_play(n, k, policy, 5, npo, 1.0, seed0 + gid)
+        g = got[gid]
+        assert len(g["z"]) == len(r["moves"]), gid
+        np.testing.assert_allclose(g["pi"], r["pi"], rtol=0, atol=1e-12)
+        assert np.array_equal(g["z"], r["z"].astype(np.float32)), gid
+        assert np.array_equal(g["states"], r["states"].astype(np.float32)), gid
+    eng.close()
+    ev.close()
