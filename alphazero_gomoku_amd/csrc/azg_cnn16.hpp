@@ -64,23 +64,22 @@ struct Cnn16Geom {
     static_assert(OTP % OC == 0, "act_fc1 output tiles must split evenly into accumulator groups");
     // f32 scratch that aliases IN + A1 once conv2 has consumed them (float offsets)
     static constexpr int HP_OFF = 0;                          // head partials [4 waves][8][NTP] (rows 6, 7 unused)
-    static constexpr int PART_OFF = 0;                        // FC partials [4 waves][NOUT][T] (HP is dead by then)
-    static constexpr int LG_OFF = PART_OFF + 4 * NOUT * T_;   // probabilities [T][S]
-    static constexpr int VAL_OFF = LG_OFF + T_ * S;           // values [T]
-    // head outputs as halves: hi [T][KPP], lo [T][KPP], hi [T][KPV], lo [T][KPV]; they start on the last
-    // wave's rows 6 and 7 of the head partials, which are written (zeros) before but never read
-    static constexpr int X_OFF = HP_OFF + 30 * NTP;
-    static constexpr int X_END = X_OFF + T_ * (KPP + KPV);
     // One-leaf kernels (T == 1): the fully connected layers run on the VALU over the NON-ZERO head
     // outputs only.  Wave w owns the inputs k = 4*i + w; its (k, x) pairs sit in lists behind the
     // head partials, the per-wave partial sums in the (by then dead) head-partial region.
     static constexpr bool SPARSE_FC = T_ == 1;
-    static constexpr int QP = S, QV = (2 * S + 3) / 4;        // list capacities per wave: policy, value
+    static constexpr int PART_OFF = 0;                        // FC partials [4 waves][NOUT][T] (HP is dead by then)
+    static constexpr int SPP_OFF = 0;                         // sparse FC: policy partials [4 waves][256]
+    static constexpr int SPV_OFF = 1024;                      // sparse FC: value partials [4 waves][4 lane groups][64]
+    static constexpr int LG_OFF = SPARSE_FC ? SPV_OFF + 1024 : PART_OFF + 4 * NOUT * T_;   // probabilities [T][S]
+    static constexpr int VAL_OFF = LG_OFF + T_ * S;           // values [T]
+    // head outputs as halves: hi [T][KPP], lo [T][KPP], hi [T][KPV], lo [T][KPV]; they start on the last
+    // wave's rows 6 and 7 of the head partials, which are written (zeros) before but never read
+    static constexpr int X_OFF = HP_OFF + 30 * NTP;
+    static constexpr int X_END = SPARSE_FC ? X_OFF : X_OFF + T_ * (KPP + KPV);
+    static constexpr int QP = S, QV = (2 * S + 3) / 4;        // sparse FC: list capacities per wave (policy, value)
     static constexpr int LP_OFF = X_OFF, LV_OFF = LP_OFF + 2 * 4 * QP, CNT_OFF = LV_OFF + 2 * 4 * QV, SP_END = CNT_OFF + 8;
-    static constexpr int SPP_OFF = 0;                         // policy partials [4 waves][256]
-    static constexpr int SPV_OFF = 2048;                      // value partials [4 waves][4 lane groups][64]
-    static_assert(!SPARSE_FC || (S <= 256 && LG_OFF >= SPP_OFF + 1024 && VAL_OFF < SPV_OFF && SPV_OFF + 1024 <= X_OFF && SP_END * 4 <= A2H_OFF),
-                  "sparse FC scratch does not fit");
+    static_assert(!SPARSE_FC || (S <= 256 && SP_END * 4 <= A2H_OFF), "sparse FC scratch does not fit");
     static_assert(VAL_OFF + T_ <= X_OFF, "FC partials and results must fit in the head-partial region");
     static_assert(X_END * 4 <= A2H_OFF, "scratch does not fit under IN+A1");
     static_assert(T_ <= 4, "one wave per position in the softmax stage");

@@ -139,11 +139,21 @@ static bool pick_search(int N, int mode, int cnn_mode, SearchLaunch *out)
     case 6: *out = f16 ? net_launch<6, 2, true>() : net_launch<6, 2, false>(); break;
     case 8: *out = f16 ? net_launch<8, AZG_T8, true>() : net_launch<8, 2, false>(); break;
     case 15: *out = f16 ? net_launch<15, 1, true>() : net_launch<15, 1, false>(); break;
+    // the other board sizes: split-f16 arithmetic only
+    case 7: if (!f16) return false; *out = net_launch<7, 2, true>(); break;
+    case 9: if (!f16) return false; *out = net_launch<9, 1, true>(); break;
+    case 10: if (!f16) return false; *out = net_launch<10, 1, true>(); break;
+    case 11: if (!f16) return false; *out = net_launch<11, 1, true>(); break;
+    case 12: if (!f16) return false; *out = net_launch<12, 1, true>(); break;
+    case 13: if (!f16) return false; *out = net_launch<13, 1, true>(); break;
+    case 14: if (!f16) return false; *out = net_launch<14, 1, true>(); break;
+    case 16: if (!f16) return false; *out = net_launch<16, 1, true>(); break;
     default: return false;
     }
 #if AZG_OCC8 == 2 && AZG_T8 == 2
     // same code, register-capped entry points (see AZG_CAPPED_SEARCH_KERNEL)
     if (f16 && N == 6) out->fn = search_kernel_f16_6x6;
+    if (f16 && N == 7) out->fn = search_kernel_f16_7x7;
     if (f16 && N == 8) out->fn = search_kernel_f16_8x8;
 #endif
     return true;
@@ -169,6 +179,14 @@ static bool pick_eval(int N, int cnn_mode, EvalLaunch *out)
     case 6: *out = f16 ? eval_launch<6, 2, true>() : eval_launch<6, 2, false>(); return true;
     case 8: *out = f16 ? eval_launch<8, 2, true>() : eval_launch<8, 2, false>(); return true;
     case 15: *out = f16 ? eval_launch<15, 1, true>() : eval_launch<15, 1, false>(); return true;
+    case 7: if (!f16) return false; *out = eval_launch<7, 2, true>(); return true;
+    case 9: if (!f16) return false; *out = eval_launch<9, 1, true>(); return true;
+    case 10: if (!f16) return false; *out = eval_launch<10, 1, true>(); return true;
+    case 11: if (!f16) return false; *out = eval_launch<11, 1, true>(); return true;
+    case 12: if (!f16) return false; *out = eval_launch<12, 1, true>(); return true;
+    case 13: if (!f16) return false; *out = eval_launch<13, 1, true>(); return true;
+    case 14: if (!f16) return false; *out = eval_launch<14, 1, true>(); return true;
+    case 16: if (!f16) return false; *out = eval_launch<16, 1, true>(); return true;
     default: return false;
     }
 }
@@ -345,7 +363,7 @@ extern "C" int azg_create(const azg_config *cfg, azg_handle **out)
     SearchLaunch sl;
     if (cfg->cnn_mode != AZG_CNN_F16X3 && cfg->cnn_mode != AZG_CNN_F32) return fail(nullptr, AZG_EINVAL, "bad cnn_mode %d", cfg->cnn_mode);
     if (!pick_search(cfg->board_n, cfg->prior_mode, cfg->cnn_mode, &sl))
-        return fail(nullptr, AZG_EINVAL, "no CNN search kernel is built for board_n=%d (built: 6, 8, 15)", cfg->board_n);
+        return fail(nullptr, AZG_EINVAL, "no CNN search kernel is built for board_n=%d with this cnn_mode (split-f16: 6..16, float32: 6, 8, 15)", cfg->board_n);
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(nullptr, AZG_EHIP, "no HIP device available");
     if (cfg->device < 0 || cfg->device >= ndev) return fail(nullptr, AZG_EINVAL, "device %d out of range (%d devices)", cfg->device, ndev);

@@ -20,7 +20,7 @@ fi
 # The split-f16 search kernels for boards up to 8x8 run two workgroups per CU and are capped at 240
 # VGPRs (azg_kernels.hpp, AZG_CAPPED_SEARCH_KERNEL), so that copy kernels can run beside them;
 # this check reports a build in which the cap did not hold.
-awk '/Function Name: _ZN3azg21search_kernel_f16_[68]x[68]ENS_8DevStateE/ { k = $0; sub(/.*Function Name: /, "", k); sub(/ .*/, "", k) }
+awk '/Function Name: _ZN3azg21search_kernel_f16_[678]x[678]ENS_8DevStateE/ { k = $0; sub(/.*Function Name: /, "", k); sub(/ .*/, "", k) }
      k != "" && / VGPRs: / { v = $0; sub(/.* VGPRs: /, "", v); sub(/ .*/, "", v);
          if (v + 0 > 240) printf("WARNING: %s uses %d VGPRs (> 240): copy kernels cannot run beside it\n", k, v);
          k = "" }' "$log" >&2

@@ -39,8 +39,8 @@ extern "C" {
 #define AZG_PRIOR_HASH       2   /* exact dyadic priors from a position hash (test)      */
 
 /* arithmetic of the CNN's 3x3 convolutions (both agree with a float32 reference to <1e-6) */
-#define AZG_CNN_F16X3      0   /* split-f16 operands, three f16 MFMAs per product, f32 accumulate */
-#define AZG_CNN_F32        1   /* float32-input MFMA                                             */
+#define AZG_CNN_F16X3      0   /* split-f16 operands, three f16 MFMAs per product, f32 accumulate; boards 6x6 .. 16x16 */
+#define AZG_CNN_F32        1   /* float32-input MFMA; boards 6x6, 8x8, 15x15                                           */
 
 /* weight tensor layouts accepted by azg_set_weights */
 #define AZG_LAYOUT_TORCH   0   /* state_dict order of policy_value_net_pytorch.py:31-41 */

@@ -256,7 +256,9 @@ def test_error_paths(az):
     with pytest.raises(az._lib.AzgError):
         az.SelfPlayEngine(4, 5, 10, 1)                       # board smaller than n_in_row
     with pytest.raises(az._lib.AzgError):
-        az.SelfPlayEngine(7, 5, 10, 1)                       # no CNN kernel for 7x7
+        az.SelfPlayEngine(5, 5, 10, 1)                       # no CNN kernel below 6x6
+    with pytest.raises(az._lib.AzgError):
+        az.SelfPlayEngine(9, 5, 10, 1, cnn_mode=az._lib.CNN_F32)   # float32 kernels exist for 6, 8, 15 only
     eng = az.SelfPlayEngine(8, 5, 10, 1)
     eng.reset_games()
     with pytest.raises(az._lib.AzgError) as e:
@@ -784,5 +786,54 @@ def test_full_batch_pipelined_games_equal_oracle_games_with_gpu_priors(az, oracl
         np.testing.assert_allclose(g["pi"], r["pi"], rtol=0, atol=1e-12)
         assert np.array_equal(g["z"], r["z"].astype(np.float32)), gid
         assert np.array_equal(g["states"], r["states"].astype(np.float32)), gid
+    eng.close()
+    ev.close()
+
+
+@pytest.mark.parametrize("n", [6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16])
+def test_cnn_and_net_search_on_every_board_size(az, oracle, n):
+    """Split-f16 CNN kernels exist for every square board from 6x6 to 16x16 (two leaves per
+    workgroup up to 8x8, one leaf with the sparse FC above): the forward pass against the oracle's
+    float64 net (1e-5; required 1e-4), and a net-driven search bit-exact against the oracle's tree fed
+    the GPU's own outputs."""
+    k, npo = min(5, n), 48
+    params = helpers.make_params(n, seed=300 + n, scale=2.0)
+    ev = az.SelfPlayEngine(n, k, 1, 1)
+    ev.set_weights(params)
+    onet = oracle.OracleNet(n, n, params, precise=True)
+    for pre in helpers.random_positions(n, k, 4, seed=n):
+        ob = oracle.OracleBoard(n, n, k)
+        ob.init_board()
+        ok = True
+        for m in pre[: n * n // 2]:
+            ob.do_move(m)
+            if ob.game_end()[0]:
+                ok = False
+                break
+        if not ok:
+            continue
+        po, vo = onet.forward(ob.current_state())
+        pg, vg = ev.eval_batch(ob.current_state()[None].astype(np.float32))
+        assert np.abs(pg[0] - po).max() < 1e-5 and abs(vg[0] - vo) < 1e-5, n
+    eng = az.SelfPlayEngine(n, k, npo, 1)
+    eng.set_weights(params)
+    eng.reset_games()
+    prefix = [(n // 2) * n + n // 2, (n // 2) * n + n // 2 + 1]
+    eng.set_position(0, stones_of(prefix), prefix[-1], 1)
+    eng.search()
+    visits, q, p, _ = eng.root_stats()
+
+    def policy(b):
+        ob = oracle.OracleBoard(n, n, k)
+        ob.b = b
+        pr, v = ev.eval_batch(ob.current_state().astype(np.float32))
+        return [float(x) for x in pr[0]], float(v[0])
+    ob = oracle.OracleBoard(n, n, k)
+    ob.init_board()
+    for m in prefix:
+        ob.do_move(m)
+    t = oracle.OracleMCTS(policy, c_puct=5, n_playout=npo)
+    acts, ovis, oq, op, _ = t.get_move_probs(ob, temp=1.0)
+    assert np.array_equal(visits[0][acts], ovis) and np.array_equal(q[0][acts], oq) and np.array_equal(p[0][acts], op), n
     eng.close()
     ev.close()
