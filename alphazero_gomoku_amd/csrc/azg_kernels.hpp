@@ -102,7 +102,7 @@ __device__ __forceinline__ void search_body(DevState st)
         int term = 0;
         if (active) {
             const TreeView tv = tree_view(st, g, gl->arena);
-            d = wave_select(st, tv, gl, lane);
+            d = wave_select<GL, false, (MODE == 0 ? (N * N + WAVE - 1) / WAVE : MAXS / WAVE)>(st, tv, gl, lane);
             if (st.NW == 1) term = game_end_1w(gl->leaf_bb[0][0], gl->leaf_bb[1][0], st.N, st.S, st.n_in_row, d.ply);
             else term = wave_game_end(gl->leaf_bb, st.N, st.S, st.n_in_row, d.ply, lane);
             if (lane == 0) { gl->term = term; gl->need_eval = term == 0; }

@@ -215,7 +215,7 @@ __global__ __launch_bounds__(256) void pure_search_kernel(DevState st, int n_pla
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
 
     for (int it = 0; it < n_playout; it++) {
-        const Descent d = wave_select<GameLds, true>(st, tv, gl, lane);
+        const Descent d = wave_select<GameLds, true, CPL>(st, tv, gl, lane);
         int ply = d.ply;
         int term = leaf_game_end(st, gl, ply, lane);
         BBox box = stones_bbox<CPL>(gl->leaf_bb, st.N, st.S, lane);

@@ -203,10 +203,11 @@ __device__ inline int game_end_1w(u64 s1, u64 s2, int N, int S, int nrow, int ns
 // ---------------------------------------------------------------- select
 // Descend from the root to a leaf (mcts_alphaZero.py:122-129).  Lanes hold one child
 // each (four at most on 16x16); the argmax keeps the first maximum in ascending child
-// order, which is the order `max()` meets them in the reference.  UNIFORM_P: every child of a
+// order, which is the order `max()` meets them in the reference.  CPL: children per lane the
+// caller's board can need.  UNIFORM_P: every child of a
 // node carries the prior 1/K in double (the rollout opponent's policy_value_fn,
 // mcts_pure.py:33-46), computed instead of loaded.
-template <class GL, bool UNIFORM_P = false>
+template <class GL, bool UNIFORM_P = false, int CPL = MAXS / WAVE>
 __device__ inline Descent wave_select(const DevState &st, const TreeView &t, GL *gl, int lane)
 {
     // leaf board starts as a copy of the root board (copy.deepcopy, :162)
@@ -225,17 +226,35 @@ __device__ inline Descent wave_select(const DevState &st, const TreeView &t, GL 
         double best = -HUGE_VAL, bq = 0.0;
         int bidx = 0x7fffffff, bchild = -1, bn = 0;
         unsigned bmeta = 0;
-        for (int i = lane; i < K; i += WAVE) {
-            const int ei = child + i;
-            const double q = t.Q[ei];
-            const double p = UNIFORM_P ? 1.0 / (double)K : (double)t.P[ei];
-            const int n = t.N[ei];
-            const int ch = t.child[ei];
-            const unsigned mt = t.meta[ei];
-            // get_value (:82-83): c_puct * P * sqrt(Np) / (1 + n), left to right, then Q + u
-            const double u = ((st.c_puct * p) * sq) / (double)(1 + n);
-            const double s = q + u;
-            if (s > best) { best = s; bq = q; bidx = i; bchild = ch; bn = n; bmeta = mt; }
+        // a node has up to 64 * CPL children (CPL: the caller's bound, all boards: MAXS / WAVE), CPL
+        // per lane: all of a lane's loads go out before the first is used (clamped index instead of
+        // a guard), one memory round trip per level
+        double q_[CPL];
+        float p_[CPL];
+        int n_[CPL], ch_[CPL];
+        unsigned mt_[CPL];
+#pragma unroll
+        for (int c = 0; c < CPL; c++) {
+            if (c * WAVE < K) {                                  // wave-uniform
+                const int i = lane + c * WAVE;
+                const int ei = child + (i < K ? i : 0);
+                q_[c] = t.Q[ei];
+                if (!UNIFORM_P) p_[c] = t.P[ei];
+                n_[c] = t.N[ei];
+                ch_[c] = t.child[ei];
+                mt_[c] = t.meta[ei];
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < CPL; c++) {
+            const int i = lane + c * WAVE;
+            if (i < K) {
+                const double p = UNIFORM_P ? 1.0 / (double)K : (double)p_[c];
+                // get_value (:82-83): c_puct * P * sqrt(Np) / (1 + n), left to right, then Q + u
+                const double u = ((st.c_puct * p) * sq) / (double)(1 + n_[c]);
+                const double s = q_[c] + u;
+                if (s > best) { best = s; bq = q_[c]; bidx = i; bchild = ch_[c]; bn = n_[c]; bmeta = mt_[c]; }
+            }
         }
         // first maximum in ascending child order: the wave maximum, then the lowest child index
         // among the lanes that hold it (a lane already kept its own first maximum)
