@@ -166,6 +166,35 @@ __device__ inline int wave_game_end(const u64 (*bb)[MAXW], int N, int S, int nro
     return nstones == S ? 3 : 0;                                 // game.py:167-168
 }
 
+// The same result from the last move alone, for a position whose predecessors had not ended (a
+// leaf below the root: a node is only expanded when its game goes on, so a winning line at the
+// leaf contains the stone just played and belongs to its mover; the reference's scan over all
+// stones then reports exactly that player).  Lane 16*d + o + 8 tests the cell o steps from the
+// last move along direction d (o = -8 .. 7, used up to n_in_row - 1); a direction wins when the
+// run of the mover's stones through the last move is at least n_in_row long.  n_in_row <= 8.
+__device__ inline int wave_last_move_end(const u64 (*bb)[MAXW], int N, int S, int nrow, int nstones, int last,
+                                         int mover, int lane)
+{
+    if (nstones >= nrow + 2) {                                   // game.py:136-137
+        const u64 *mine = bb[mover - 1];
+        const int d = lane >> 4, o = (lane & 15) - 8;
+        const int dr = d == 0 ? 0 : 1, dc = d == 1 ? 0 : (d == 3 ? -1 : 1);
+        const int r0 = last / N, c0 = last - r0 * N;
+        const int r = r0 + o * dr, c = c0 + o * dc;
+        const bool on = o > -nrow && o < nrow && r >= 0 && r < N && c >= 0 && c < N && bb_has(mine, r * N + c);
+        const u64 m = __ballot(on);
+        for (int k = 0; k < 4; k++) {
+            const unsigned w = (unsigned)(m >> (16 * k)) & 0xFFFFu;
+            const unsigned up = ~(w >> 8) & 0x1FFu;              // bits 8..15 -> 0..7, bit 8 forced zero stop
+            const int n_up = __ffs((int)up) - 1;                 // stones at offsets 0, 1, ... (the last move included)
+            const unsigned dn = ~w & 0xFFu;                      // zeros among offsets -8 .. -1 (bits 0..7)
+            const int n_dn = dn ? 7 - (31 - __clz((int)dn)) : 8; // stones at offsets -1, -2, ...
+            if (n_up + n_dn >= nrow) return mover;
+        }
+    }
+    return nstones == S ? 3 : 0;                                 // game.py:167-168
+}
+
 // The same test for boards of at most 64 cells (one word per colour), as whole-board bit
 // operations: bit c of the anchor set is on when cells c, c+d, ..., c+(n-1)d are all the
 // player's and the ray stays on the board (the reference's range tests, game.py:143-157).
