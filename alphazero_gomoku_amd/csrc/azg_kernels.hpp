@@ -103,10 +103,10 @@ __device__ __forceinline__ void search_body(DevState st)
         if (active) {
             const TreeView tv = tree_view(st, g, gl->arena);
             d = wave_select<GL, false, (MODE == 0 ? (N * N + WAVE - 1) / WAVE : MAXS / WAVE)>(st, tv, gl, lane);
-            if (st.NW == 1) term = game_end_1w(gl->leaf_bb[0][0], gl->leaf_bb[1][0], st.N, st.S, st.n_in_row, d.ply);
-            else if (d.depth > 1 && st.n_in_row <= 8)
+            if (d.depth > 1 && st.n_in_row <= 8)
                 term = wave_last_move_end(gl->leaf_bb, st.N, st.S, st.n_in_row, d.ply, d.last,
                                           player_at(gl->first_player, d.ply - 1), lane);
+            else if (st.NW == 1) term = game_end_1w(gl->leaf_bb[0][0], gl->leaf_bb[1][0], st.N, st.S, st.n_in_row, d.ply);
             else term = wave_game_end(gl->leaf_bb, st.N, st.S, st.n_in_row, d.ply, lane);
             if (lane == 0) { gl->term = term; gl->need_eval = term == 0; }
             n_eval += term == 0;

@@ -217,7 +217,10 @@ __global__ __launch_bounds__(256) void pure_search_kernel(DevState st, int n_pla
     for (int it = 0; it < n_playout; it++) {
         const Descent d = wave_select<GameLds, true, CPL>(st, tv, gl, lane);
         int ply = d.ply;
-        int term = leaf_game_end(st, gl, ply, lane);
+        // below the root only the stone just played can have ended the game (see wave_last_move_end)
+        int term = (d.depth > 1 && st.n_in_row <= 8)
+                       ? wave_last_move_end(gl->leaf_bb, st.N, st.S, st.n_in_row, ply, d.last, player_at(gl->first_player, ply - 1), lane)
+                       : leaf_game_end(st, gl, ply, lane);
         BBox box = stones_bbox<CPL>(gl->leaf_bb, st.N, st.S, lane);
         bool tgt[CPL];
         u64 mask[CPL];
@@ -237,7 +240,9 @@ __global__ __launch_bounds__(256) void pure_search_kernel(DevState st, int n_pla
             if (ply == 0) { box.top = box.bottom = r; box.left = box.right = c; }
             else { box.top = max(box.top, r); box.bottom = min(box.bottom, r); box.left = min(box.left, c); box.right = max(box.right, c); }
             ply++;
-            term = leaf_game_end(st, gl, ply, lane);
+            term = st.n_in_row <= 8
+                       ? wave_last_move_end(gl->leaf_bb, st.N, st.S, st.n_in_row, ply, move, player_at(gl->first_player, ply - 1), lane)
+                       : leaf_game_end(st, gl, ply, lane);
             if (!term) K = move_targets<CPL>(gl->leaf_bb, box, ply, st.N, st.S, lane, tgt, mask);
         }
         const double leaf_value = term == 3 ? 0.0 : (term == player ? 1.0 : -1.0);
