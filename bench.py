@@ -26,8 +26,8 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 FLOP_PER_EVAL = {6: 6.79e6, 8: 12.09e6, 15: 42.80e6}    # 188416*S + 8*S*S + 128, 2 flop / MAC
 PEAK_TFLOPS = {"f16x3": 2500.0, "f32": 157.3}            # dense MFMA peaks of MI355X: f16 inputs / f32 inputs
 # HBM bytes per search launch from rocprofv3 PMC passes (FETCH_SIZE + WRITE_SIZE, separate runs,
-# profiles/r1_m_pmc_search_kernel.json); only valid for the default workload and build
-PMC_TRAFFIC_BYTES = {("f16x3", 8, 400, 1024): (269157.3 + 564014.9) * 1024.0}
+# profiles/r1_n_pmc_search_kernel.json); only valid for the default workload and build
+PMC_TRAFFIC_BYTES = {("f16x3", 8, 400, 1024): (269291.4 + 570463.6) * 1024.0}
 
 
 def random_init_params(n, device):
