@@ -400,12 +400,15 @@ __device__ inline void fc16_run(gptr<half8> w, int ks_total, FcRing<NTG, KW> &r,
     }
 }
 
+#ifndef AZG_SPARSE_FC_ROWS
+#define AZG_SPARSE_FC_ROWS 32
+#endif
 // The tail of a one-leaf forward pass (T == 1, the 15x15 kernels): head outputs, then both wide
 // fully connected layers as sparse matrix-vector products on the VALU.  With one leaf the FC
 // layers are bound by streaming their weights from L2 (0.8 MB for 15x15), and about half of the
 // ReLU'd head outputs are exactly zero: only the weight rows of non-zero inputs are read.
 // Wave w compacts and multiplies the inputs k = 4*i + w; a lane owns four consecutive outputs
-// (16-byte loads, 16 rows in flight per wave).  Sums are float32 in a fixed order.
+// (16-byte loads, 32 rows of 1 KB in flight per wave).  Sums are float32 in a fixed order.
 template <class G>
 __device__ inline void cnn16_tail_sparse(const NetWeights &nw, float *lds, int tid, Prof &prof)
 {
@@ -449,17 +452,18 @@ __device__ inline void cnn16_tail_sparse(const NetWeights &nw, float *lds, int t
     {
         const gptr<f32x4> wrow = as_global(reinterpret_cast<const f32x4 *>(nw.wpfc_k)) + lane;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        for (int i0 = 0; i0 < np; i0 += 16) {
-            f32x4 wv[16];
-            float xv[16];
+        constexpr int U = AZG_SPARSE_FC_ROWS;                                // weight rows (1 KB each) in flight per wave
+        for (int i0 = 0; i0 < np; i0 += U) {
+            f32x4 wv[U];
+            float xv[U];
 #pragma unroll
-            for (int u = 0; u < 16; u++) {
+            for (int u = 0; u < U; u++) {
                 const Pair e = lp[i0 + u < np ? i0 + u : np - 1];            // clamp: keeps the load unconditional
                 xv[u] = i0 + u < np ? e.x : 0.0f;
                 wv[u] = wrow[(size_t)e.k * 64];
             }
 #pragma unroll
-            for (int u = 0; u < 16; u++)
+            for (int u = 0; u < U; u++)
 #pragma unroll
                 for (int j = 0; j < 4; j++) acc[j] = __builtin_fmaf(wv[u][j], xv[u], acc[j]);
         }
