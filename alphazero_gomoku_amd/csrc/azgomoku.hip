@@ -3,10 +3,15 @@
 #include "../../include/azgomoku.h"
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cmath>
+#include <condition_variable>
+#include <mutex>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <cstdlib>
 #include <string>
 #include <thread>
@@ -19,6 +24,66 @@
 using namespace azg;
 
 static thread_local std::string g_create_error;
+
+// Worker threads of one handle that draw the exploration noise of a move step (make_noise).  They
+// are started on first use and sleep between steps; the calling thread takes chunks as well.
+struct NoisePool {
+    std::vector<std::thread> workers;
+    std::mutex m;
+    std::condition_variable wake, done;
+    unsigned long long round = 0;
+    int running = 0, chunks = 0;
+    bool stop = false;
+    std::atomic<int> next{0};
+    const std::function<void(int)> *job = nullptr;
+
+    void drain()
+    {
+        for (int c = next.fetch_add(1); c < chunks; c = next.fetch_add(1)) (*job)(c);
+    }
+    void loop()
+    {
+        unsigned long long seen = 0;
+        std::unique_lock<std::mutex> lk(m);
+        for (;;) {
+            wake.wait(lk, [&] { return stop || round != seen; });
+            if (stop) return;
+            seen = round;
+            lk.unlock();
+            drain();
+            lk.lock();
+            if (--running == 0) done.notify_one();
+        }
+    }
+    // runs job(0) .. job(n_chunks - 1), each exactly once, and returns when all are finished
+    void run(int n_chunks, int n_threads, const std::function<void(int)> &fn)
+    {
+        if (n_threads <= 1 || n_chunks <= 1) {
+            for (int c = 0; c < n_chunks; c++) fn(c);
+            return;
+        }
+        while ((int)workers.size() < n_threads - 1) workers.emplace_back([this] { loop(); });
+        {
+            std::lock_guard<std::mutex> lk(m);
+            job = &fn; chunks = n_chunks; next.store(0);
+            running = (int)workers.size();
+            round++;
+        }
+        wake.notify_all();
+        drain();
+        std::unique_lock<std::mutex> lk(m);
+        done.wait(lk, [&] { return running == 0; });
+    }
+    ~NoisePool()
+    {
+        {
+            std::lock_guard<std::mutex> lk(m);
+            stop = true;
+        }
+        wake.notify_all();
+        for (auto &t : workers) t.join();
+    }
+};
 
 struct azg_handle {
     azg_config cfg{};
@@ -34,6 +99,9 @@ struct azg_handle {
     std::vector<unsigned char> h_drained, h_fin_bank;
     std::vector<long long> h_game_id, h_fin_id;
     std::vector<NpLegacyRng> rng;
+    NoisePool noise_pool;
+    double noise_ms = 0.0;            // host time spent drawing noise since the last azg_host_timing
+    long long noise_steps = 0;
     // pinned staging
     double *h_noise = nullptr, *h_u = nullptr;
     int *h_moves = nullptr;
@@ -700,13 +768,16 @@ static void make_noise(azg_handle *h)
             h->h_u[g] = h->rng[g].next_double();
         }
     };
+    const auto t0 = std::chrono::steady_clock::now();
     int nthr = (int)std::min<unsigned>(8, std::max(1u, std::thread::hardware_concurrency()));
     if (B < 64) nthr = 1;
-    if (nthr == 1) { work(0, B); return; }
-    std::vector<std::thread> pool;
-    const int per = (B + nthr - 1) / nthr;
-    for (int i = 0; i < nthr; i++) pool.emplace_back(work, std::min(B, i * per), std::min(B, (i + 1) * per));
-    for (auto &t : pool) t.join();
+    // chunks of 16 games handed out through a counter: games near their end draw far fewer
+    // gamma variates than games at their start, so equal ranges would not be equal work
+    const int per = 16, chunks = (B + per - 1) / per;
+    const std::function<void(int)> job = [&](int c) { work(c * per, std::min(B, (c + 1) * per)); };
+    h->noise_pool.run(chunks, nthr, job);
+    h->noise_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    h->noise_steps++;
 }
 
 static int advance_common(azg_handle *h, double temp, const int32_t *given, int flags, int32_t *moves_out, double *pi_out)
@@ -1139,6 +1210,16 @@ extern "C" int azg_debug_stamps(azg_handle *h, long long out[kStampWords])
     HIPCHK(h, hipStreamSynchronize(h->stream));
     HIPCHK(h, hipMemcpy(out, h->st.stamps, kStampWords * sizeof(long long), hipMemcpyDeviceToHost));
     HIPCHK(h, hipMemset(h->st.stamps, 0, kStampWords * sizeof(long long)));
+    return AZG_OK;
+}
+
+extern "C" int azg_host_timing(azg_handle *h, double *noise_ms, int64_t *noise_steps)
+{
+    if (!h) return AZG_EINVAL;
+    if (noise_ms) *noise_ms = h->noise_ms;
+    if (noise_steps) *noise_steps = h->noise_steps;
+    h->noise_ms = 0.0;
+    h->noise_steps = 0;
     return AZG_OK;
 }
 

@@ -235,6 +235,12 @@ class SelfPlayEngine:
         self._chk(self.L.azg_profile(self.h, C.byref(a), C.byref(b), C.byref(c)))
         return a.value, b.value, c.value
 
+    def host_timing(self):
+        """(host milliseconds spent drawing exploration noise, move steps) since the last call."""
+        a, b = C.c_double(0.0), C.c_int64(0)
+        self._chk(self.L.azg_host_timing(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def stream(self):
         return self.L.azg_stream(self.h)
 
@@ -282,7 +288,11 @@ class SelfPlayRunner:
         self.seeds = np.zeros(B, dtype=np.uint32)
         self.live = np.zeros(B, dtype=bool)
         self.next_k = 0
-        self.games_done = self.plies_done = self.steps = 0
+        # games_done counts a game in the step it ends; games_delivered and plies_done count it
+        # when its samples reach on_samples (pipelined: one step later), so plies_done /
+        # games_delivered is a mean over whole games
+        self.games_done = self.games_delivered = self.plies_done = self.steps = 0
+        self._undelivered = 0
 
     def _assign(self, slots):
         mask = np.zeros(self.e.B, dtype=np.uint8)
@@ -306,6 +316,8 @@ class SelfPlayRunner:
             self._assign(range(self.e.B))
 
     def _deliver(self, n):
+        self.games_delivered += self._undelivered
+        self._undelivered = 0
         if n:
             out = self.e.selfplay_fetch(n, device=self.device_samples)
             self.plies_done += n
@@ -326,6 +338,7 @@ class SelfPlayRunner:
             self.steps += 1
             self.games_done += nfin
             self._deliver(ready)
+            self._undelivered = nfin
             return nfin, ready
         e.search()
         e.sample_and_advance(self.temp, want_pi=False)
@@ -351,6 +364,7 @@ class SelfPlayRunner:
             if self.on_samples is not None:
                 self.on_samples(out)
             self.games_done += nfin
+            self.games_delivered += nfin
             self.plies_done += nsamp
             self._assign(np.nonzero(fin)[0])
         return nfin, nsamp

@@ -25,9 +25,28 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 FLOP_PER_EVAL = {6: 6.79e6, 8: 12.09e6, 15: 42.80e6}    # 188416*S + 8*S*S + 128, 2 flop / MAC
 PEAK_TFLOPS = {"f16x3": 2500.0, "f32": 157.3}            # dense MFMA peaks of MI355X: f16 inputs / f32 inputs
-# HBM bytes per search launch from rocprofv3 PMC passes (FETCH_SIZE + WRITE_SIZE, separate runs,
-# profiles/r1_n_pmc_search_kernel.json); only valid for the default workload and build
-PMC_TRAFFIC_BYTES = {("f16x3", 8, 400, 1024): (269291.4 + 570463.6) * 1024.0}
+# the reference's own Python path (mcts_alphaZero.py + policy_value_net_numpy.py), one thread, measured
+# where the reference could be imported (another box): games/s at the per-game settings
+REFERENCE_PYTHON_GAMES_PER_S = {(8, 400): 0.0290, (6, 200): 0.1165}
+
+
+def pmc_traffic(cnn, n, playouts, games):
+    """HBM bytes per search launch from the newest committed rocprofv3 --pmc summary of the default
+    workload (profiles/*pmc_search_kernel*.json: FETCH_SIZE and WRITE_SIZE from separate passes, in
+    KiB).  None for any other workload or when no summary travels with the tree."""
+    import glob
+    if (cnn, n, playouts, games) != ("f16x3", 8, 400, 1024):
+        return None, None
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_search_kernel*.json")),
+                   key=lambda f: (len(os.path.basename(f).split("_")[0]), os.path.basename(f)))
+    for f in reversed(files):
+        try:
+            with open(f) as fh:
+                d = json.load(fh)
+            return (d["FETCH_SIZE"]["mean_of_last_4"] + d["WRITE_SIZE"]["mean_of_last_4"]) * 1024.0, os.path.basename(f)
+        except (OSError, KeyError, ValueError):
+            continue
+    return None, None
 
 
 def random_init_params(n, device):
@@ -45,7 +64,12 @@ def cpu_baseline(n, k, n_playout, params_np, seconds_hint=25.0):
     host cores: one whole game per thread, float32 net."""
     from oracle import az_oracle
     az_oracle.build()
-    threads = max(1, min(16, os.cpu_count() or 1))
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = os.cpu_count() or 1
+    # a one-GPU share of the host is 16 cores; os.cpu_count() shows the whole machine
+    threads = max(1, min(16, usable))
     net = az_oracle.OracleNet(n, n, params_np, precise=False)
     t0 = time.time()
     total_plies, plies, _ = az_oracle.self_play_many(n, k, net, 5.0, n_playout, 1.0, 0, threads, threads)
@@ -59,8 +83,59 @@ def cpu_baseline(n, k, n_playout, params_np, seconds_hint=25.0):
                       "C restatement of the reference's Python path, float32 net"
                       % (threads, threads - 1, total_plies, total_plies * n_playout, dt),
             "playouts_per_s": total_plies * n_playout / dt,
+            "nproc": os.cpu_count(), "cores_usable": usable,
             "single_core": {"value": 1.0 / dt1, "unit": "games/s", "cores": 1,
-                            "sample": "1 game (seed 0), %d plies in %.1f s" % (plies1, dt1)}}
+                            "sample": "1 game (seed 0), %d plies in %.1f s" % (plies1, dt1)},
+            "reference_python_other_box": {"value": REFERENCE_PYTHON_GAMES_PER_S.get((n, n_playout)), "unit": "games/s",
+                                           "cores": 1, "sample": "the reference's Python (mcts_alphaZero.py + numpy net), 3 games, "
+                                                                 "measured on the 8-vCPU build container, not on this box"}}
+
+
+def visit_l1_vs_cpu(az, az_oracle, n, k, n_playout, params, params_np, samples, device, cnn_mode, count=8):
+    """Per-move visit-count L1 between the GPU search and the CPU oracle's search (its own float64
+    forward pass on the same float32 weights), both from a fresh root on positions taken from the
+    self-play games of the timed run: sum_a |N_gpu(a) - N_cpu(a)| / sum_a N_cpu(a)."""
+    st = samples["states"][:4096].to("cpu").numpy()
+    if not len(st):
+        return None
+    pick = np.linspace(0, len(st) - 1, count).astype(int)
+    eng = az.SelfPlayEngine(n, k, n_playout, count, 5.0, device=device, cnn_mode=cnn_mode)
+    eng.set_weights(params)
+    eng.reset_games()
+    net = az_oracle.OracleNet(n, n, params_np, precise=True)
+    boards = []
+    for slot, i in enumerate(pick):
+        pl = st[i][:, ::-1, :]                                  # plane row r shows board row n-1-r
+        mine = [int(c) for c in np.flatnonzero(pl[0].reshape(-1) > 0)]
+        theirs = [int(c) for c in np.flatnonzero(pl[1].reshape(-1) > 0)]
+        lastc = [int(c) for c in np.flatnonzero(pl[2].reshape(-1) > 0)]
+        last = lastc[0] if lastc else -1
+        cur = 1 if pl[3][0][0] > 0 else 2                       # stone 1 opens: it is to move at even ply
+        stones = {c: cur for c in mine}
+        stones.update({c: 3 - cur for c in theirs})
+        eng.set_position(slot, stones, last, cur)
+        p1 = [c for c, p in stones.items() if p == 1 and c != last]
+        p2 = [c for c, p in stones.items() if p == 2 and c != last]
+        if last >= 0:
+            (p1 if stones[last] == 1 else p2).append(last)
+        ob = az_oracle.OracleBoard(n, n, k)
+        ob.init_board()
+        for t in range(len(p1) + len(p2)):
+            ob.do_move(p1[t // 2] if t % 2 == 0 else p2[t // 2])
+        boards.append(ob)
+    eng.search()
+    visits, _, _, _ = eng.root_stats()
+    eng.close()
+    l1 = []
+    for slot, ob in enumerate(boards):
+        t = az_oracle.OracleMCTS("net", c_puct=5, n_playout=n_playout, net=net)
+        acts, ovis, _, _, _ = t.get_move_probs(ob, temp=1.0)
+        cpu = np.zeros(n * n)
+        cpu[acts] = ovis
+        l1.append(float(np.abs(visits[slot] - cpu).sum() / max(1.0, cpu.sum())))
+    return {"mean": float(np.mean(l1)), "max": float(np.max(l1)), "positions": int(count),
+            "identical": int(sum(1 for x in l1 if x == 0.0)), "n_playout": n_playout,
+            "note": "fresh-root searches from positions of the timed run's games; CPU side = oracle tree + its float64 net"}
 
 
 def main():
@@ -73,6 +148,8 @@ def main():
     ap.add_argument("--n-in-row", type=int, default=5)
     ap.add_argument("--playouts", type=int, default=400)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--preroll-max", type=int, default=600,
+                    help="upper bound of the untimed pre-roll steps that bring the slot population to steady state")
     ap.add_argument("--host-refill", action="store_true",
                     help="restart finished slots from the host between steps instead of the pipelined azg_selfplay_* calls")
     ap.add_argument("--cnn", choices=["f16x3", "f32"], default="f16x3",
@@ -131,6 +208,16 @@ def main():
         mine["states"] = mine["states"].to(torch.uint8)   # the planes are 0/1: exact, a quarter of the bytes on the links
         return int(azdist.gather_samples(mine)["z"].shape[0])
 
+    # Untimed, declared pre-roll: all slots start together on empty boards, so right after the
+    # start the games that end are the short ones of ONE cohort.  Steps run until every slot has
+    # turned over at least twice and three mean game lengths have passed; from then on games end at
+    # the steady rate slots / mean length per step, whatever --warmup and --steps are.
+    preroll = 0
+    while preroll < args.preroll_max:
+        run.step()
+        preroll += 1
+        if run.games_delivered >= 2 * args.games and preroll >= 3.0 * run.plies_done / run.games_delivered:
+            break
     for _ in range(args.warmup):
         run.step()
     if use_dist:
@@ -140,7 +227,7 @@ def main():
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
-    g0, p0 = run.games_done, run.plies_done
+    g0 = run.games_done
     t0 = time.perf_counter()
     for _ in range(args.steps):
         run.step()
@@ -152,23 +239,29 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t0
     run.finish()
-    games, plies = run.games_done - g0, run.plies_done - p0
+    games = run.games_done - g0
+    # mean game length over every game of the run (pre-roll included): whole games only
+    all_games, plies = run.games_delivered, run.plies_done
     launches, kernel_ms, evals = eng.profile()
+    host = eng.host_timing()
 
-    stats = torch.tensor([dt, games, plies, evals, kernel_ms, launches], dtype=torch.float64, device=dev)
+    stats = torch.tensor([dt, games, plies, evals, kernel_ms, launches, all_games, preroll], dtype=torch.float64, device=dev)
     if use_dist:
         mx = stats.clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         sm = stats.clone()
         dist.all_reduce(sm, op=dist.ReduceOp.SUM)
         dt = float(mx[0])
-        games, plies, evals = float(sm[1]), float(sm[2]), float(sm[3])
+        games, plies, evals, all_games = float(sm[1]), float(sm[2]), float(sm[3]), float(sm[6])
         kernel_ms, launches = float(sm[4]) / world, float(sm[5]) / world
+        preroll = int(mx[7])
     if rank == 0:
         flop = FLOP_PER_EVAL.get(n, 188416.0 * n * n + 8.0 * n ** 4 + 128)
         # per-GPU dominant kernel: leaf-eval flops of one launch / its HIP-event duration
         evals_per_gpu = evals / world
         achieved = flop * evals_per_gpu / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else 0.0
+        plies_per_game = plies / all_games if all_games else None
+        traffic, traffic_src = pmc_traffic(args.cnn, n, args.playouts, args.games)
         out = {
             "metric": "completed self-play games/sec, %dx%d board n_playout=%d" % (n, n, args.playouts),
             "value": games / dt, "unit": "games/s", "n_gpus": world, "steps": args.steps,
@@ -182,14 +275,19 @@ def main():
                                    % (n, n, k, args.playouts, args.games),
                        "games_in_flight_per_gpu": args.games, "sharding": "game id mod n_gpus",
                        "step": "one move (n_playout playouts + sample/advance/re-root) for every slot"},
-            "games_completed": games, "plies_per_game": plies / games if games else None,
+            "games_completed": games, "plies_per_game": plies_per_game,
+            "preroll_steps": preroll, "games_before_timed_region": all_games - games,
+            # self-check of `value`: in steady state games end at slots / (mean length) per step
+            "value_from_plies": (args.games * world / (plies_per_game * dt / args.steps)) if plies_per_game else None,
             "playouts_per_s": evals / dt, "samples_gathered": gathered,
+            "host_noise_ms_per_step": host[0] / host[1] if host[1] else None,
             "roofline": {"bound": "mfma", "kernel": "search_kernel (fused select + leaf CNN + expand + backup)",
                          "achieved": achieved, "peak": PEAK_TFLOPS[args.cnn], "unit": "TFLOP/s",
                          "frac": achieved / PEAK_TFLOPS[args.cnn],
-                         "traffic": PMC_TRAFFIC_BYTES.get((args.cnn, n, args.playouts, args.games)),
-                         "traffic_note": "HBM bytes per launch, FETCH_SIZE + WRITE_SIZE of a separate rocprofv3 --pmc run "
-                                         "(tree arrays; 4-8 B per lane accesses, no width correction applied)",
+                         "traffic": traffic, "traffic_source": traffic_src,
+                         "traffic_note": "HBM bytes per launch, (FETCH_SIZE + WRITE_SIZE) * 1024 of separate rocprofv3 --pmc "
+                                         "passes; the tree arrays move as 4-8 B per lane accesses, for which gfx950's FETCH_SIZE "
+                                         "is uncalibrated (it halves 16 B per lane streams): the read share may be up to 2x larger",
                          "note": "achieved counts the ALGORITHMIC flops of the leaf CNN (12.09 MFLOP per evaluation at 8x8); "
                                  "the f16x3 path issues ~2.9x that many MFMA flops",
                          "launches": launches, "avg_launch_ms": kernel_ms / launches if launches else None,
@@ -204,7 +302,12 @@ def main():
                                          "note": "same kernel; %.1f KB of tree/board traffic per playout, latency-bound "
                                                  "pointer chasing inside the fused launch" % (tree_bytes / 1e3)}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(n, k, args.playouts, [p.cpu().numpy() for p in params])
+            params_np = [p.cpu().numpy() for p in params]
+            out["cpu_baseline"] = cpu_baseline(n, k, args.playouts, params_np)
+            if drained:
+                from oracle import az_oracle
+                out["visit_l1_vs_cpu"] = visit_l1_vs_cpu(az, az_oracle, n, k, args.playouts, params, params_np, drained[-1],
+                                                         local_rank, az._lib.CNN_F16X3 if args.cnn == "f16x3" else az._lib.CNN_F32)
         print(json.dumps(out))
     eng.close()
     if use_dist:

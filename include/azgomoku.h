@@ -198,6 +198,11 @@ int azg_equi_data(azg_handle *h, int n, const float *states, const double *pi, c
  * evaluations (playouts that reached the CNN).  Resets the counters. */
 int azg_profile(azg_handle *h, int64_t *launches, double *ms, int64_t *playouts);
 
+/* Host-side cost of the exploration noise (the numpy-legacy Dirichlet and uniform draws of
+ * mcts_alphaZero.py:236-240, generated on host threads while a search runs): summed wall
+ * milliseconds and number of move steps since the last call.  Resets the counters. */
+int azg_host_timing(azg_handle *h, double *noise_ms, int64_t *noise_steps);
+
 /* The handle's HIP stream (hipStream_t), for callers that record their own events. */
 void *azg_stream(azg_handle *h);
 
