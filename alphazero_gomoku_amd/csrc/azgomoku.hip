@@ -85,12 +85,47 @@ struct NoisePool {
     }
 };
 
+// Scratch of azg_board_step_batch_static: one fixed array per GPU (every device that loads this
+// code object holds its own copy at its own address), so that entry point never allocates.  In host
+// code the array's name is only a handle for hipGetSymbolAddress; the device address of each GPU's
+// copy is looked up once per device (static_scratch_ptr) and used everywhere else.
+constexpr int kStaticMaxBoards = 1024;                       // boards per call, any supported board size
+constexpr size_t kStaticStonesOff = 0;                                                  // u64 [n][2][MAXW]
+constexpr size_t kStaticIntsOff = kStaticStonesOff + (size_t)kStaticMaxBoards * 2 * MAXW * 8;   // i32 ply|last|moves|player [4][max]
+constexpr size_t kStaticBadOff = kStaticIntsOff + (size_t)4 * kStaticMaxBoards * 4;     // i32 [4] illegal-move flag
+constexpr size_t kStaticEndOff = kStaticBadOff + 16;                                    // u8 [max] ended
+constexpr size_t kStaticWinOff = kStaticEndOff + kStaticMaxBoards;                      // i8 [max] winner
+constexpr size_t kStaticPlanesOff = kStaticWinOff + kStaticMaxBoards;                   // f32 [max][4][MAXS]
+constexpr size_t kStaticBytes = kStaticPlanesOff + (size_t)kStaticMaxBoards * 4 * MAXS * 4;
+static __device__ __align__(256) unsigned char scratch[kStaticBytes];
+
+constexpr int kMaxDevices = 64;
+static std::mutex g_static_mutex;
+static unsigned char *g_static_ptr[kMaxDevices] = {nullptr};
+
+// Device address of this GPU's copy of `scratch`; the device must be current.
+static hipError_t static_scratch_ptr(int device, unsigned char **out)
+{
+    if (device < 0 || device >= kMaxDevices) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> lk(g_static_mutex);
+    if (!g_static_ptr[device]) {
+        void *p = nullptr;
+        const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess) return e;
+        g_static_ptr[device] = static_cast<unsigned char *>(p);
+    }
+    *out = g_static_ptr[device];
+    return hipSuccess;
+}
+
 struct azg_handle {
     azg_config cfg{};
     DevState st{};
     hipStream_t stream = nullptr;
     std::string err;
     std::vector<void *> allocs;
+    unsigned char *static_scratch = nullptr;     // this device's copy of the file-scope scratch array
+    int *h_static_bad = nullptr;                 // pinned: illegal-move flag read back by the static entry point
     bool have_weights = false;
     float *d_weights = nullptr;
     // host mirrors, refreshed after every state-changing call
@@ -337,6 +372,7 @@ extern "C" void azg_destroy(azg_handle *h)
     if (h->h_u) (void)hipHostFree(h->h_u);
     if (h->h_moves) (void)hipHostFree(h->h_moves);
     if (h->h_mirror) (void)hipHostFree(h->h_mirror);
+    if (h->h_static_bad) (void)hipHostFree(h->h_static_bad);
     if (h->sp.h_map) (void)hipHostFree(h->sp.h_map);
     if (h->sp.h_ids) (void)hipHostFree(h->sp.h_ids);
     if (h->sp.ev_mirror) (void)hipEventDestroy(h->sp.ev_mirror);
@@ -353,6 +389,8 @@ static int create_impl(azg_handle *h)
     const int N = c.board_n, S = N * N, B = c.n_games;
     HIPCHK(h, hipSetDevice(c.device));
     HIPCHK(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    HIPCHK(h, static_scratch_ptr(c.device, &h->static_scratch));
+    HIPCHK(h, hipHostMalloc((void **)&h->h_static_bad, 16));
     DevState &st = h->st;
     st.N = N; st.S = S; st.NW = (S + 63) / 64; st.n_in_row = c.n_in_row; st.B = B;
     st.prior_mode = c.prior_mode; st.n_playout = c.n_playout; st.c_puct = c.c_puct;
@@ -999,6 +1037,53 @@ extern "C" int azg_board_step_batch(azg_handle *h, int n, uint64_t *stones, int3
     if (planes) HIPCHK(h, hipMemcpyAsync(planes, d_planes, (size_t)n * 4 * S * 4, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     if (bad) return fail(h, AZG_EMOVE, "illegal move in batch (occupied cell, out of range, or bad player)");
+    return AZG_OK;
+}
+
+// The same step with no allocation anywhere on the way: staging, the illegal-move flag and the
+// outputs live in this GPU's copy of the file-scope `scratch` array (address looked up once per
+// device in azg_create).  Calls on one GPU share that array, so calls that overlap on one GPU race.
+extern "C" int azg_board_step_batch_static(azg_handle *h, int n, uint64_t *stones, int32_t *ply, int32_t *last_move,
+                                           const int32_t *moves, const int32_t *player, uint8_t *ended, int8_t *winner,
+                                           float *planes)
+{
+    if (!h || n < 0 || !stones || !ply || !last_move || !moves || !player || !ended || !winner)
+        return fail(h, AZG_EINVAL, "null argument");
+    if (n > kStaticMaxBoards)
+        return fail(h, AZG_EINVAL, "azg_board_step_batch_static takes at most %d boards per call, got %d", kStaticMaxBoards, n);
+    if (n == 0) return AZG_OK;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    const int S = h->st.S;
+    unsigned char *d = h->static_scratch;                     // device address, never the array's name
+    const size_t sb = (size_t)n * 2 * MAXW * 8, si = (size_t)n * 4;
+    u64 *d_st = (u64 *)(d + kStaticStonesOff);
+    int *d_ply = (int *)(d + kStaticIntsOff), *d_last = d_ply + kStaticMaxBoards, *d_mv = d_last + kStaticMaxBoards,
+        *d_pl = d_mv + kStaticMaxBoards, *d_bad = (int *)(d + kStaticBadOff);
+    unsigned char *d_end = d + kStaticEndOff;
+    signed char *d_win = (signed char *)(d + kStaticWinOff);
+    float *d_planes = (float *)(d + kStaticPlanesOff);
+    HIPCHK(h, hipMemcpyAsync(d_st, stones, sb, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(d_ply, ply, si, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(d_last, last_move, si, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(d_mv, moves, si, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(d_pl, player, si, hipMemcpyHostToDevice, h->stream));
+    // the array keeps the previous call's contents: the flag must start at zero, and a board the
+    // kernel rejects writes neither `ended` nor `winner`
+    HIPCHK(h, hipMemsetAsync(d_bad, 0, 16, h->stream));
+    HIPCHK(h, hipMemsetAsync(d_end, 0, (size_t)2 * kStaticMaxBoards, h->stream));
+    hipLaunchKernelGGL(board_step_kernel, dim3((n + 3) / 4), dim3(256), 0, h->stream, h->st.N, h->st.n_in_row, n,
+                       d_st, d_ply, d_last, (const int *)d_mv, (const int *)d_pl, d_end, d_win,
+                       planes ? d_planes : (float *)nullptr, d_bad);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipMemcpyAsync(h->h_static_bad, d_bad, 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(stones, d_st, sb, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(ply, d_ply, si, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(last_move, d_last, si, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(ended, d_end, n, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(winner, d_win, n, hipMemcpyDeviceToHost, h->stream));
+    if (planes) HIPCHK(h, hipMemcpyAsync(planes, d_planes, (size_t)n * 4 * S * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (h->h_static_bad[0]) return fail(h, AZG_EMOVE, "illegal move in batch (occupied cell, out of range, or bad player)");
     return AZG_OK;
 }
 

@@ -211,8 +211,9 @@ class SelfPlayEngine:
         self._chk(self.L.azg_eval_batch(self.h, _ptr(st), n, _ptr(probs), _ptr(vals)))
         return probs, vals
 
-    def board_step_batch(self, stones, ply, last_move, moves, player, want_planes=True):
-        """In-place Board.do_move + game_end (+ current_state) on n boards."""
+    def board_step_batch(self, stones, ply, last_move, moves, player, want_planes=True, static=False):
+        """In-place Board.do_move + game_end (+ current_state) on n boards.  static=True goes
+        through azg_board_step_batch_static (no device allocation, at most 1024 boards)."""
         n = int(ply.shape[0])
         assert stones.dtype == np.uint64 and stones.shape == (n, 2, 4) and stones.flags.c_contiguous
         assert ply.dtype == np.int32 and last_move.dtype == np.int32
@@ -222,7 +223,8 @@ class SelfPlayEngine:
         winner = np.zeros(n, dtype=np.int8)
         planes = np.zeros((n, 4, self.N, self.N), dtype=np.float32) if want_planes else None
         i32 = C.POINTER(C.c_int32)
-        self._chk(self.L.azg_board_step_batch(
+        fn = self.L.azg_board_step_batch_static if static else self.L.azg_board_step_batch
+        self._chk(fn(
             self.h, n, stones.ctypes.data_as(C.POINTER(C.c_uint64)), ply.ctypes.data_as(i32),
             last_move.ctypes.data_as(i32), mv.ctypes.data_as(i32), pl.ctypes.data_as(i32),
             ended.ctypes.data_as(C.POINTER(C.c_uint8)), winner.ctypes.data_as(C.POINTER(C.c_int8)),

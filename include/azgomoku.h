@@ -185,6 +185,17 @@ int azg_board_step_batch(azg_handle *h, int n, uint64_t *stones, int32_t *ply,
                          int32_t *last_move, const int32_t *moves, const int32_t *player,
                          uint8_t *ended, int8_t *winner, float *planes);
 
+/* azg_board_step_batch for callers that cannot allocate device memory (code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc).  It has no counterpart in the
+ * reference.  Same arguments, results and errors as azg_board_step_batch, but staging, the
+ * illegal-move flag and the outputs live in a fixed 4.3 MB array that every GPU running this
+ * library holds until the process ends, and the call makes no hipMalloc / hipFree of any kind.
+ * At most 1024 boards per call (AZG_EINVAL beyond that).  All calls on one GPU share that array:
+ * calls that overlap in time on one GPU race, whatever handle they use. */
+int azg_board_step_batch_static(azg_handle *h, int n, uint64_t *stones, int32_t *ply,
+                                int32_t *last_move, const int32_t *moves, const int32_t *player,
+                                uint8_t *ended, int8_t *winner, float *planes);
+
 /* TrainPipeline.get_equi_data (train.py:116-135): the 8 rotated / mirrored images of n
  * (state, pi, z) tuples (layout of azg_drain_samples), tuple i giving outputs 8i..8i+7
  * in the reference's order (rotation by 90, its left-right mirror, rotation by 180, ...).
