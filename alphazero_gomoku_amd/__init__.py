@@ -7,13 +7,13 @@ package needs the built library alphazero_gomoku_amd/libazgomoku.so; there is no
 CPU fallback."""
 from . import _lib
 from .board import Board
-from .engine import PRIOR_HASH, PRIOR_NET, PRIOR_UNIFORM32, SelfPlayEngine
+from .engine import PRIOR_HASH, PRIOR_NET, PRIOR_PEAKED, PRIOR_UNIFORM32, SelfPlayEngine
 from .game import Game
 from .mcts import MCTSPlayer
 from .mcts_pure import MCTSPlayer as MCTS_Pure
 
 __all__ = ["Board", "Game", "MCTSPlayer", "MCTS_Pure", "PolicyValueNet", "SelfPlayEngine", "PRIOR_NET",
-           "PRIOR_UNIFORM32", "PRIOR_HASH"]
+           "PRIOR_UNIFORM32", "PRIOR_HASH", "PRIOR_PEAKED"]
 
 
 def __getattr__(name):

@@ -7,7 +7,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # AZG_LIBRARY selects another build of the same library (A/B timing of kernel variants)
 LIB_PATH = os.environ.get("AZG_LIBRARY") or os.path.join(_HERE, "libazgomoku.so")
 
-PRIOR_NET, PRIOR_UNIFORM32, PRIOR_HASH = 0, 1, 2
+PRIOR_NET, PRIOR_UNIFORM32, PRIOR_HASH, PRIOR_PEAKED = 0, 1, 2, 3
 LAYOUT_TORCH, LAYOUT_THEANO = 0, 1
 CNN_F16X3, CNN_F32 = 0, 1
 
@@ -20,7 +20,7 @@ SYMBOLS = ["azg_create", "azg_destroy", "azg_last_error", "azg_set_weights", "az
            "azg_advance", "azg_update_with_move", "azg_status", "azg_states",
            "azg_drain_samples", "azg_eval_batch", "azg_board_step_batch", "azg_profile",
            "azg_stream", "azg_selfplay_begin", "azg_selfplay_step", "azg_selfplay_fetch",
-           "azg_selfplay_end", "azg_equi_data", "azg_pure_search", "azg_host_timing",
+           "azg_selfplay_end", "azg_equi_data", "azg_pure_search", "azg_host_timing", "azg_arena_stats",
            "azg_board_step_batch_static"]
 
 
@@ -33,7 +33,8 @@ class AzgError(RuntimeError):
 class Config(C.Structure):
     _fields_ = [("board_n", C.c_int32), ("n_in_row", C.c_int32), ("n_playout", C.c_int32),
                 ("n_games", C.c_int32), ("c_puct", C.c_double), ("device", C.c_int32),
-                ("prior_mode", C.c_int32), ("arena_nodes", C.c_int32), ("cnn_mode", C.c_int32)]
+                ("prior_mode", C.c_int32), ("arena_nodes", C.c_int32), ("cnn_mode", C.c_int32),
+                ("big_arenas", C.c_int32)]
 
 
 _lib = None
@@ -101,6 +102,7 @@ def load():
     L.azg_board_step_batch.argtypes = [vp, C.c_int, u64p, i32p, i32p, i32p, i32p, u8p, i8p, f32p]
     L.azg_board_step_batch_static.argtypes = [vp, C.c_int, u64p, i32p, i32p, i32p, i32p, u8p, i8p, f32p]
     L.azg_host_timing.argtypes = [vp, f64p, i64p]
+    L.azg_arena_stats.argtypes = [vp, i64p, i64p]
     L.azg_pure_search.argtypes = [vp, C.c_int, C.POINTER(C.c_uint32), i32p]
     L.azg_profile.argtypes = [vp, i64p, f64p, i64p]
     L.azg_stream.argtypes = [vp]

@@ -158,6 +158,15 @@ struct DevState {
     int *eChild;                   // [B][2][cap] first child edge or -1
     unsigned *eMeta;               // [B][2][cap] action | children << 16
     int *used;                     // [B] edges in use in the live arena
+    // large arenas for the few games whose re-used tree outgrows the standard one (a sharply peaked
+    // net keeps most of the previous search below the move played: root visits approach
+    // n_playout / (1 - share of the chosen child)).  cap_big holds ANY tree: after t moves a root has
+    // at most (t+1)*n_playout visits and a node at most S-t children, (t+1)(S-t) <= ((S+1)/2)^2.
+    int cap_big, n_big;
+    int *big_of;                   // [B] large arena the game lives in, or -1
+    int *big_owner;                // [n_big] slot that owns the large arena, or -1
+    float *bP; int *bN; double *bQ; int *bChild; unsigned *bMeta;   // [n_big][2][cap_big]
+    unsigned long long *arena_stats;   // [2] moves into a large arena | trees dropped because none was free
     unsigned char *cur;            // [B]
     long long *evals;              // [B] leaf evaluations that needed priors (profiling)
     // per-game training samples, two banks per slot: the game in progress records into bank

@@ -15,7 +15,7 @@ __device__ inline void wg_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wo
 
 // ---------------------------------------------------------------- search
 // MCTS.get_move_probs' playout loop (mcts_alphaZero.py:161-163) for T games.
-// MODE: AZG_PRIOR_NET (0), UNIFORM32 (1), HASH (2).  F16: CNN on split-f16 operands
+// MODE: AZG_PRIOR_NET (0), UNIFORM32 (1), HASH (2), PEAKED (3).  F16: CNN on split-f16 operands
 // (azg_cnn16.hpp) instead of float32 MFMA (azg_cnn.hpp).
 template <int N, int T, bool F16>
 struct GeomPick { using type = typename std::conditional<F16, Cnn16Geom<N, T>, CnnGeom<N, T>>::type; };
@@ -88,6 +88,8 @@ __device__ __forceinline__ void search_body(DevState st)
     if (active && lane == 0) {
         gl->arena = st.cur[g];
         gl->used = st.used[g];
+        gl->big = st.big_of[g];
+        gl->cap = arena_cap(st, g);
         gl->root_act = meta_act(tree_view(st, g, st.cur[g]).meta[0]);
     }
     wave_sync();
@@ -101,9 +103,11 @@ __device__ __forceinline__ void search_body(DevState st)
         Descent d = {0, 0, 0, 0};
         int term = 0;
         if (active) {
-            const TreeView tv = tree_view(st, g, gl->arena);
+            const TreeView tv = tree_view(st, g, gl->arena, gl->big);
             d = wave_select<GL, false, (MODE == 0 ? (N * N + WAVE - 1) / WAVE : MAXS / WAVE)>(st, tv, gl, lane);
-            if (d.depth > 1 && st.n_in_row <= 8)
+            // (with n_in_row < 3 a line can exist before the reference's n_in_row + 2 stone threshold
+            // lets it count, so it need not contain the last stone: full scan there)
+            if (d.depth > 1 && st.n_in_row >= 3 && st.n_in_row <= 8)
                 term = wave_last_move_end(gl->leaf_bb, st.N, st.S, st.n_in_row, d.ply, d.last,
                                           player_at(gl->first_player, d.ply - 1), lane);
             else if (st.NW == 1) term = game_end_1w(gl->leaf_bb[0][0], gl->leaf_bb[1][0], st.N, st.S, st.n_in_row, d.ply);
@@ -134,7 +138,7 @@ __device__ __forceinline__ void search_body(DevState st)
                 d.leaf = gl->leaf; d.depth = gl->depth; d.ply = gl->leaf_ply; d.last = gl->leaf_last;
                 term = gl->term;
             }
-            const TreeView tv = tree_view(st, g, gl->arena);
+            const TreeView tv = tree_view(st, g, gl->arena, gl->big);
             const int cur_player = player_at(gl->first_player, d.ply);
             double v;
             if (term) {
@@ -147,6 +151,15 @@ __device__ __forceinline__ void search_body(DevState st)
             } else if (MODE == 1) {
                 const float p = 1.0f / (float)(st.S - d.ply);
                 wave_expand(st, tv, gl, d, g, lane, [=](int) { return p; });
+                v = 0.0;
+            } else if (MODE == 3) {
+                // one child carries almost all of the prior: the lowest empty cell
+                int low = st.S;
+                for (int w = st.NW - 1; w >= 0; w--) {
+                    const u64 freew = ~(gl->leaf_bb[0][w] | gl->leaf_bb[1][w]);
+                    if (freew) low = w * 64 + __ffsll((long long)freew) - 1;
+                }
+                wave_expand(st, tv, gl, d, g, lane, [=](int c) { return c == low ? 0.9375f : 0.0009765625f; });
                 v = 0.0;
             } else {
                 const u64 key = state_key(gl->leaf_bb, st.NW, cur_player);
@@ -258,9 +271,15 @@ __device__ inline size_t sample_index(const DevState &st, int g, int bank, int t
 }
 
 // Start a fresh root (TreeNode(None, 1.0), mcts_alphaZero.py:108,192) in arena `arena`.
+// A game that lived in a large arena gives it back.  One lane.
 __device__ inline void fresh_root(const DevState &st, int g, int arena)
 {
-    TreeView t = tree_view(st, g, arena);
+    const int big = st.big_of[g];
+    if (big >= 0) {
+        st.big_of[g] = -1;
+        __hip_atomic_store(&st.big_owner[big], -1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    TreeView t = tree_view(st, g, arena, -1);
     t.P[0] = 1.0f; t.N[0] = 0; t.Q[0] = 0.0; t.child[0] = -1; t.meta[0] = meta_pack(0xFFFF, 0);
     st.used[g] = 1;
     st.cur[g] = (unsigned char)arena;
@@ -328,6 +347,35 @@ __device__ inline void wave_reroot(const DevState &st, int g, int c, int lane)
         scan = chunk_end;
     }
     if (lane == 0) { st.used[g] = freep; st.cur[g] = (unsigned char)na; }
+}
+
+// After a re-root: the next search adds at most n_playout nodes of at most S - ply children.  A
+// tree that could outgrow its standard arena that way moves to a large arena (sized for any tree)
+// BEFORE the search, so the search itself never runs out of room; edge indices are arena-relative,
+// so the move is a plain copy.  When no large arena is free the tree is dropped instead (a fresh
+// root: the game goes on without the re-used statistics) and counted in arena_stats[1].
+__device__ inline void wave_fit_arena(const DevState &st, int g, int ply, int lane)
+{
+    wg_fence();
+    const int used = st.used[g];
+    if (st.big_of[g] >= 0 || (long long)used + (long long)st.n_playout * (st.S - ply) <= (long long)st.cap) return;
+    int slot = -1;
+    if (lane == 0) {
+        for (int p = 0; p < st.n_big; p++)
+            if (atomicCAS(&st.big_owner[p], -1, g) == -1) { slot = p; break; }
+    }
+    slot = __shfl(slot, 0);
+    const int a = st.cur[g];
+    if (slot < 0) {
+        if (lane == 0) { fresh_root(st, g, a); atomicAdd(&st.arena_stats[1], 1ULL); }
+        return;
+    }
+    const TreeView o = tree_view(st, g, a, -1), n = tree_view(st, g, a, slot);
+    for (int i = lane; i < used; i += WAVE) {
+        n.P[i] = o.P[i]; n.N[i] = o.N[i]; n.Q[i] = o.Q[i]; n.child[i] = o.child[i]; n.meta[i] = o.meta[i];
+    }
+    wg_fence();
+    if (lane == 0) { st.big_of[g] = slot; atomicAdd(&st.arena_stats[0], 1ULL); }
 }
 
 // MCTSPlayer.get_action's tail (mcts_alphaZero.py:216-242) + Game.start_self_play's
@@ -441,8 +489,7 @@ __global__ __launch_bounds__(256) void advance_kernel(DevState st, double temp, 
         const int mover = player_at(st.first_player[g], ply);
         if (lane < 2 * MAXW) ((u64 *)s_bbw[wave])[lane] = st.bb[(size_t)g * 2 * MAXW + lane];
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-        const bool occupied = bb_has(s_bbw[wave][0], move) || bb_has(s_bbw[wave][1], move);
-        if (occupied || move < 0 || move >= S) {
+        if (move < 0 || move >= S || bb_has(s_bbw[wave][0], move) || bb_has(s_bbw[wave][1], move)) {
             if (lane == 0) st.err[g] |= 2;
             return;
         }
@@ -462,6 +509,7 @@ __global__ __launch_bounds__(256) void advance_kernel(DevState st, double temp, 
             if (lane == 0) fresh_root(st, g, st.cur[g]);      // reset_player / unknown move
         } else {
             wave_reroot(st, g, base + child_idx, lane);
+            wave_fit_arena(st, g, (flags & ADV_BOARD) ? ply + 1 : ply, lane);
         }
     }
     if ((flags & ADV_RESTART) && ended) {
@@ -509,7 +557,10 @@ __global__ __launch_bounds__(256) void reroot_kernel(DevState st, const int *mov
             if (m) { child_idx = i0 + __ffsll((long long)m) - 1; break; }
         }
     if (child_idx < 0) { if (lane == 0) fresh_root(st, g, st.cur[g]); }
-    else wave_reroot(st, g, base + child_idx, lane);
+    else {
+        wave_reroot(st, g, base + child_idx, lane);
+        wave_fit_arena(st, g, st.ply[g], lane);
+    }
 }
 
 // ---------------------------------------------------------------- reset / set position

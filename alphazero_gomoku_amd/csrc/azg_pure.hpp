@@ -156,7 +156,7 @@ __device__ inline bool wave_expand_targets(const DevState &st, const TreeView &t
                                            int lane, const bool (&tgt)[CPL], const u64 (&mask)[CPL], int K)
 {
     const int base = gl->used;
-    if (base + K > st.cap) {
+    if (base + K > gl->cap) {
         if (lane == 0) st.err[g] |= 1;
         return false;
     }
@@ -202,7 +202,7 @@ __global__ __launch_bounds__(256) void pure_search_kernel(DevState st, int n_pla
     const TreeView tv = tree_view(st, g, arena);
     if (lane < 2 * MAXW) ((u64 *)gl->root_bb)[lane] = st.bb[(size_t)g * 2 * MAXW + lane];
     if (lane == 0) {
-        gl->live = 1; gl->gid = g; gl->arena = arena;
+        gl->live = 1; gl->gid = g; gl->arena = arena; gl->big = st.big_of[g]; gl->cap = arena_cap(st, g);
         gl->root_ply = st.ply[g]; gl->root_last = st.last_move[g]; gl->first_player = st.first_player[g];
         // TreeNode(None, 1.0) (mcts_pure.py:139, :243)
         tv.P[0] = 1.0f; tv.N[0] = 0; tv.Q[0] = 0.0; tv.child[0] = -1; tv.meta[0] = meta_pack(0xFFFF, 0);
@@ -218,7 +218,7 @@ __global__ __launch_bounds__(256) void pure_search_kernel(DevState st, int n_pla
         const Descent d = wave_select<GameLds, true, CPL>(st, tv, gl, lane);
         int ply = d.ply;
         // below the root only the stone just played can have ended the game (see wave_last_move_end)
-        int term = (d.depth > 1 && st.n_in_row <= 8)
+        int term = (d.depth > 1 && st.n_in_row >= 3 && st.n_in_row <= 8)
                        ? wave_last_move_end(gl->leaf_bb, st.N, st.S, st.n_in_row, ply, d.last, player_at(gl->first_player, ply - 1), lane)
                        : leaf_game_end(st, gl, ply, lane);
         BBox box = stones_bbox<CPL>(gl->leaf_bb, st.N, st.S, lane);
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(256) void pure_search_kernel(DevState st, int n_pla
             if (ply == 0) { box.top = box.bottom = r; box.left = box.right = c; }
             else { box.top = max(box.top, r); box.bottom = min(box.bottom, r); box.left = min(box.left, c); box.right = max(box.right, c); }
             ply++;
-            term = st.n_in_row <= 8
+            term = (st.n_in_row >= 3 && st.n_in_row <= 8)
                        ? wave_last_move_end(gl->leaf_bb, st.N, st.S, st.n_in_row, ply, move, player_at(gl->first_player, ply - 1), lane)
                        : leaf_game_end(st, gl, ply, lane);
             if (!term) K = move_targets<CPL>(gl->leaf_bb, box, ply, st.N, st.S, lane, tgt, mask);

@@ -45,6 +45,8 @@ struct GameLdsT {
     int term;                  // leaf ended: 0 no, 1/2 winner, 3 tie
     int need_eval;             // leaf needs priors/value from the provider
     int gid;                   // slot index
+    int big;                   // large arena the game lives in, or -1 (DevState::big_of during a launch)
+    int cap;                   // edges the game's arena holds
 };
 typedef GameLdsT<MAXS + 1> GameLds;
 
@@ -52,14 +54,23 @@ struct TreeView {              // live arena of one game
     float *P; int *N; double *Q; int *child; unsigned *meta;
 };
 
-__device__ inline TreeView tree_view(const DevState &st, int g, int arena)
+// big: DevState::big_of[g] (the large arena the game lives in, or -1)
+__device__ inline TreeView tree_view(const DevState &st, int g, int arena, int big)
 {
-    size_t off = ((size_t)g * 2 + (size_t)arena) * (size_t)st.cap;
     TreeView t;
-    t.P = st.eP + off; t.N = st.eN + off; t.Q = st.eQ + off;
-    t.child = st.eChild + off; t.meta = st.eMeta + off;
+    if (big >= 0) {
+        const size_t off = ((size_t)big * 2 + (size_t)arena) * (size_t)st.cap_big;
+        t.P = st.bP + off; t.N = st.bN + off; t.Q = st.bQ + off;
+        t.child = st.bChild + off; t.meta = st.bMeta + off;
+    } else {
+        const size_t off = ((size_t)g * 2 + (size_t)arena) * (size_t)st.cap;
+        t.P = st.eP + off; t.N = st.eN + off; t.Q = st.eQ + off;
+        t.child = st.eChild + off; t.meta = st.eMeta + off;
+    }
     return t;
 }
+__device__ inline TreeView tree_view(const DevState &st, int g, int arena) { return tree_view(st, g, arena, st.big_of[g]); }
+__device__ inline int arena_cap(const DevState &st, int g) { return st.big_of[g] >= 0 ? st.cap_big : st.cap; }
 
 // Lanes of one wave exchange data through LDS (one lane writes, others read).  The
 // hardware executes a wave's LDS instructions in order, but the compiler sees 64
@@ -327,7 +338,7 @@ __device__ inline bool wave_expand(const DevState &st, const TreeView &t, GL *gl
     const int leaf = d.leaf;
     const int K = st.S - d.ply;
     const int base = gl->used;
-    if (base + K > st.cap) {
+    if (base + K > gl->cap) {
         if (lane == 0) st.err[g] |= 1;
         return false;
     }

@@ -237,6 +237,7 @@ static bool pick_search(int N, int mode, int cnn_mode, SearchLaunch *out)
 {
     if (mode == AZG_PRIOR_UNIFORM32) { *out = {search_kernel<0, 4, 1, false>, 4, 4 * sizeof(GameLds)}; return true; }
     if (mode == AZG_PRIOR_HASH) { *out = {search_kernel<0, 4, 2, false>, 4, 4 * sizeof(GameLds)}; return true; }
+    if (mode == AZG_PRIOR_PEAKED) { *out = {search_kernel<0, 4, 3, false>, 4, 4 * sizeof(GameLds)}; return true; }
     const bool f16 = cnn_mode == AZG_CNN_F16X3;
     switch (N) {
     case 6: *out = f16 ? net_launch<6, 2, true>() : net_launch<6, 2, false>(); break;
@@ -420,6 +421,23 @@ static int create_impl(azg_handle *h)
     if ((rc = dev_alloc(h, &st.eChild, E, false))) return rc;
     if ((rc = dev_alloc(h, &st.eMeta, E, false))) return rc;
     if ((rc = dev_alloc(h, &st.used, B))) return rc;
+    // large arenas (see DevState): as many as asked for, by default 16, within 16 GB
+    st.cap_big = 2 + c.n_playout * ((S + 1) / 2) * ((S + 1) / 2);
+    st.n_big = c.big_arenas < 0 ? 0 : std::min(B, c.big_arenas > 0 ? c.big_arenas : 16);
+    if (c.big_arenas <= 0)
+        while (st.n_big > 0 && (size_t)st.n_big * 2 * st.cap_big * 24 > ((size_t)16 << 30)) st.n_big--;
+    if (st.cap_big <= st.cap) st.n_big = 0;                  // the standard arenas already hold any tree
+    const size_t EB = (size_t)st.n_big * 2 * st.cap_big;
+    if ((rc = dev_alloc(h, &st.big_of, B, false))) return rc;
+    if ((rc = dev_alloc(h, &st.big_owner, st.n_big, false))) return rc;
+    HIPCHK(h, hipMemsetAsync(st.big_of, 0xFF, (size_t)B * sizeof(int), h->stream));
+    HIPCHK(h, hipMemsetAsync(st.big_owner, 0xFF, std::max<size_t>(st.n_big, 1) * sizeof(int), h->stream));
+    if ((rc = dev_alloc(h, &st.bP, EB, false))) return rc;
+    if ((rc = dev_alloc(h, &st.bN, EB, false))) return rc;
+    if ((rc = dev_alloc(h, &st.bQ, EB, false))) return rc;
+    if ((rc = dev_alloc(h, &st.bChild, EB, false))) return rc;
+    if ((rc = dev_alloc(h, &st.bMeta, EB, false))) return rc;
+    if ((rc = dev_alloc(h, &st.arena_stats, 2))) return rc;
     if ((rc = dev_alloc(h, &st.cur, B))) return rc;
     if ((rc = dev_alloc(h, &st.evals, B))) return rc;
     if ((rc = dev_alloc(h, &st.s_bb, (size_t)B * 2 * S * 2 * MAXW, false))) return rc;
@@ -465,7 +483,7 @@ extern "C" int azg_create(const azg_config *cfg, azg_handle **out)
         return fail(nullptr, AZG_EINVAL, "board width and height can not be less than n_in_row (%d)", cfg->n_in_row);
     if (cfg->n_games < 1) return fail(nullptr, AZG_EINVAL, "n_games must be positive");
     if (cfg->n_playout < 1) return fail(nullptr, AZG_EINVAL, "n_playout must be positive");
-    if (cfg->prior_mode < 0 || cfg->prior_mode > 2) return fail(nullptr, AZG_EINVAL, "bad prior_mode %d", cfg->prior_mode);
+    if (cfg->prior_mode < 0 || cfg->prior_mode > 3) return fail(nullptr, AZG_EINVAL, "bad prior_mode %d", cfg->prior_mode);
     SearchLaunch sl;
     if (cfg->cnn_mode != AZG_CNN_F16X3 && cfg->cnn_mode != AZG_CNN_F32) return fail(nullptr, AZG_EINVAL, "bad cnn_mode %d", cfg->cnn_mode);
     if (!pick_search(cfg->board_n, cfg->prior_mode, cfg->cnn_mode, &sl))
@@ -1295,6 +1313,21 @@ extern "C" int azg_debug_stamps(azg_handle *h, long long out[kStampWords])
     HIPCHK(h, hipStreamSynchronize(h->stream));
     HIPCHK(h, hipMemcpy(out, h->st.stamps, kStampWords * sizeof(long long), hipMemcpyDeviceToHost));
     HIPCHK(h, hipMemset(h->st.stamps, 0, kStampWords * sizeof(long long)));
+    return AZG_OK;
+}
+
+extern "C" int azg_arena_stats(azg_handle *h, int64_t *moved_to_large, int64_t *trees_dropped)
+{
+    if (!h) return AZG_EINVAL;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    unsigned long long v[2] = {0, 0};
+    // on the copy stream when self-play is pipelined: a search in flight must not be waited for
+    hipStream_t s = (h->sp.active && h->sp.copy_stream) ? h->sp.copy_stream : h->stream;
+    HIPCHK(h, hipMemcpyAsync(h->h_static_bad, h->st.arena_stats, sizeof(v), hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipStreamSynchronize(s));
+    memcpy(v, h->h_static_bad, sizeof(v));
+    if (moved_to_large) *moved_to_large = (int64_t)v[0];
+    if (trees_dropped) *trees_dropped = (int64_t)v[1];
     return AZG_OK;
 }
 

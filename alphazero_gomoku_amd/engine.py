@@ -4,7 +4,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import PRIOR_HASH, PRIOR_NET, PRIOR_UNIFORM32  # noqa: F401
+from ._lib import PRIOR_HASH, PRIOR_NET, PRIOR_PEAKED, PRIOR_UNIFORM32  # noqa: F401
 
 
 def _ptr(a, typ=C.c_void_p):
@@ -18,13 +18,13 @@ class SelfPlayEngine:
     and Game.start_self_play (game.py:360-416) of the reference."""
 
     def __init__(self, board_n=8, n_in_row=5, n_playout=400, n_games=1, c_puct=5.0, device=0,
-                 prior_mode=PRIOR_NET, arena_nodes=0, cnn_mode=_lib.CNN_F16X3):
+                 prior_mode=PRIOR_NET, arena_nodes=0, cnn_mode=_lib.CNN_F16X3, big_arenas=0):
         self.L = _lib.load()
         self.N, self.S, self.B = int(board_n), int(board_n) ** 2, int(n_games)
         self.n_in_row, self.n_playout, self.c_puct = int(n_in_row), int(n_playout), float(c_puct)
         self.device, self.prior_mode = int(device), int(prior_mode)
         cfg = _lib.Config(self.N, self.n_in_row, self.n_playout, self.B, self.c_puct, self.device,
-                          self.prior_mode, int(arena_nodes), int(cnn_mode))
+                          self.prior_mode, int(arena_nodes), int(cnn_mode), int(big_arenas))
         h = C.c_void_p()
         rc = self.L.azg_create(C.byref(cfg), C.byref(h))
         if rc != 0:
@@ -237,6 +237,12 @@ class SelfPlayEngine:
         self._chk(self.L.azg_profile(self.h, C.byref(a), C.byref(b), C.byref(c)))
         return a.value, b.value, c.value
 
+    def arena_stats(self):
+        """(games moved into a large tree arena, trees dropped because none was free) since creation."""
+        a, b = C.c_int64(0), C.c_int64(0)
+        self._chk(self.L.azg_arena_stats(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def host_timing(self):
         """(host milliseconds spent drawing exploration noise, move steps) since the last call."""
         a, b = C.c_double(0.0), C.c_int64(0)
@@ -259,9 +265,11 @@ class SelfPlayEngine:
         run = SelfPlayRunner(self, temp, seed0, first_game_id, game_id_stride, n_games_total, sink,
                              pipelined=pipelined)
         run.start()
-        while run.games_done < n_games_total and (max_moves is None or run.steps < max_moves):
-            run.step()
-        run.finish()
+        try:
+            while run.games_done < n_games_total and (max_moves is None or run.steps < max_moves):
+                run.step()
+        finally:
+            run.finish()                                     # leaves the handle usable after an error, too
         samples = None
         if collected:
             samples = {k: np.concatenate([c[k] for c in collected]) for k in collected[0]}

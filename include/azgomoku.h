@@ -29,7 +29,8 @@ extern "C" {
 #define AZG_EINVAL       -1   /* bad argument / unsupported configuration          */
 #define AZG_EHIP         -2   /* a HIP runtime call failed                         */
 #define AZG_ENOWEIGHTS   -3   /* net-driven search requested before azg_set_weights */
-#define AZG_EARENA       -4   /* a game's tree outgrew its arena (raise arena_nodes) */
+#define AZG_EARENA       -4   /* a game's tree outgrew its arena: arena_nodes < n_playout, or
+                                 repeated searches without a move in between (raise arena_nodes) */
 #define AZG_ESTATE       -5   /* call not valid in the current state               */
 #define AZG_EMOVE        -6   /* illegal move (occupied cell / out of range)       */
 
@@ -37,6 +38,8 @@ extern "C" {
 #define AZG_PRIOR_NET        0   /* policy/value CNN (policy_value_net_pytorch.py:23-57) */
 #define AZG_PRIOR_UNIFORM32  1   /* P = float(1)/float(K), v = 0 (test callback)         */
 #define AZG_PRIOR_HASH       2   /* exact dyadic priors from a position hash (test)      */
+#define AZG_PRIOR_PEAKED     3   /* P = 15/16 on the lowest empty cell, 1/1024 elsewhere,
+                                    v = 0 (test: trees that keep growing under tree reuse) */
 
 /* arithmetic of the CNN's 3x3 convolutions (both agree with a float32 reference to <1e-6) */
 #define AZG_CNN_F16X3      0   /* split-f16 operands, three f16 MFMAs per product, f32 accumulate; boards 6x6 .. 16x16 */
@@ -58,6 +61,8 @@ typedef struct azg_config {
     int32_t prior_mode;    /* AZG_PRIOR_*                                             */
     int32_t arena_nodes;   /* expanded nodes kept per game tree; 0 = 4*n_playout+64   */
     int32_t cnn_mode;      /* AZG_CNN_*                                               */
+    int32_t big_arenas;    /* large tree arenas shared by the games whose re-used tree outgrows
+                              arena_nodes; 0 = 16 (fewer if they would exceed 16 GB), < 0 = none */
 } azg_config;
 
 /* MCTSPlayer.__init__ / MCTS.__init__ (mcts_alphaZero.py:98-111,201-203) plus
@@ -208,6 +213,13 @@ int azg_equi_data(azg_handle *h, int n, const float *states, const double *pi, c
  * number of launches since the last call, summed milliseconds, and summed leaf
  * evaluations (playouts that reached the CNN).  Resets the counters. */
 int azg_profile(azg_handle *h, int64_t *launches, double *ms, int64_t *playouts);
+
+/* The reference's tree is unbounded under tree reuse (mcts_alphaZero.py:183-192 keeps the whole
+ * subtree of the move played).  A game whose tree may outgrow its arena during the next search is
+ * moved, before that search, into one of big_arenas large arenas that hold any tree of the
+ * configuration; if none is free its tree is dropped (the game goes on from a fresh root, without
+ * the carried-over statistics).  Counts since azg_create: games moved, trees dropped. */
+int azg_arena_stats(azg_handle *h, int64_t *moved_to_large, int64_t *trees_dropped);
 
 /* Host-side cost of the exploration noise (the numpy-legacy Dirichlet and uniform draws of
  * mcts_alphaZero.py:236-240, generated on host threads while a search runs): summed wall

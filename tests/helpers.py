@@ -99,3 +99,36 @@ def choice_index(probs, u):
     cdf = np.cumsum(np.asarray(probs, dtype=np.float64))
     cdf /= cdf[-1]
     return int(min(np.searchsorted(cdf, u, side="right"), len(cdf) - 1))
+
+
+# ---- fixtures made of records (lists of flat dicts) stored as plain arrays -----------------------
+def pack_records(name, records):
+    """-> {"name/count": n, "name/i/key": array}: scalars, strings, lists and arrays of a list of
+    flat dicts as plain numeric / unicode arrays, so the archive loads with allow_pickle=False."""
+    out = {name + "/count": np.int64(len(records))}
+    for i, r in enumerate(records):
+        for key, v in r.items():
+            a = np.asarray(v)
+            assert a.dtype != object, (name, i, key)
+            out["%s/%d/%s" % (name, i, key)] = a
+    return out
+
+
+def load_golden(fname):
+    """An .npz fixture without unpickling anything: plain entries as they are, record lists
+    (see pack_records) rebuilt as lists of dicts with Python scalars for 0-d entries."""
+    out, recs = {}, {}
+    with np.load(os.path.join(GOLDEN, fname), allow_pickle=False) as z:
+        for key in z.files:
+            parts = key.split("/")
+            if len(parts) == 2 and parts[1] == "count":
+                recs.setdefault(parts[0], {})
+                out[parts[0]] = [dict() for _ in range(int(z[key]))]
+            elif len(parts) == 3:
+                recs.setdefault(parts[0], {})[(int(parts[1]), parts[2])] = z[key]
+            else:
+                out[key] = z[key]
+    for name, items in recs.items():
+        for (i, key), a in items.items():
+            out[name][i][key] = a.item() if a.ndim == 0 else a
+    return out

@@ -14,7 +14,7 @@ G = helpers.GOLDEN
 
 
 def load(name):
-    return np.load(os.path.join(G, name), allow_pickle=True)
+    return helpers.load_golden(name)
 
 
 @pytest.fixture(scope="module")
@@ -249,6 +249,87 @@ def test_sqrt_is_correctly_rounded_on_device(az):
     t = az_oracle.OracleMCTS("hash", c_puct=5, n_playout=3000)
     acts, ovis, oq, _, _ = t.get_move_probs(ob, temp=1.0)
     assert rn[0] == 3000 and np.array_equal(visits[0][acts], ovis) and np.array_equal(q[0][acts], oq)
+    eng.close()
+
+
+def _forced_line(az, oracle, eng, policy, n, k, npo, plies, slots):
+    """Search, compare the root statistics of `slots` with the oracle's tree (which keeps the subtree
+    of every move played, mcts_alphaZero.py:183-192), play the most visited child everywhere."""
+    ob = oracle.OracleBoard(n, n, k)
+    ob.init_board()
+    t = oracle.OracleMCTS(policy, c_puct=5, n_playout=npo)
+    for ply in range(plies):
+        eng.search()
+        visits, q, _, rn = eng.root_stats()
+        acts, ovis, oq, _, _ = t.get_move_probs(ob, temp=1.0)
+        for g in slots:
+            assert rn[g] == t.root_visits() and np.array_equal(visits[g][acts], ovis), (ply, g)
+            assert np.array_equal(q[g][acts], oq), (ply, g)
+        mv = int(acts[np.argmax(ovis)])
+        eng.advance(np.full(eng.B, mv, dtype=np.int32))
+        t.update_with_move(mv)
+        ob.do_move(mv)
+        if ob.game_end()[0]:
+            break
+    return ply
+
+
+def test_trees_that_outgrow_their_arena_move_to_a_large_one(az, oracle):
+    """Tree reuse keeps the subtree of the move played, so a tree has no fixed bound in the
+    reference.  With arenas barely larger than one search, every game must move into a large arena
+    before its second search and still match the oracle visit for visit, Q for Q."""
+    n, k, npo = 8, 5, 100
+    eng = az.SelfPlayEngine(n, k, npo, 3, prior_mode=az.PRIOR_HASH, arena_nodes=npo + 4)
+    eng.reset_games()
+    plies = _forced_line(az, oracle, eng, "hash", n, k, npo, 12, (0, 1, 2))
+    moved, dropped = eng.arena_stats()
+    assert plies >= 6 and moved == 3 and dropped == 0
+    # a finished or reset game gives its large arena back: the next games can use it again
+    eng.reset_games()
+    _forced_line(az, oracle, eng, "hash", n, k, npo, 4, (0, 1, 2))
+    assert eng.arena_stats() == (6, 0)
+    eng.close()
+    # one large arena for four games that all need one: one game keeps its tree and stays exact, the
+    # others lose theirs (fresh root: exactly n_playout root visits after the next search), nobody fails
+    eng = az.SelfPlayEngine(n, k, npo, 4, prior_mode=az.PRIOR_HASH, arena_nodes=npo + 4, big_arenas=1)
+    eng.reset_games()
+    eng.search()
+    visits, _, _, _ = eng.root_stats()
+    mv = int(np.argmax(visits[0]))
+    eng.advance(np.full(4, mv, dtype=np.int32))
+    assert eng.arena_stats() == (1, 3)
+    _, _, _, rn0 = eng.root_stats()
+    eng.search()
+    _, _, _, rn = eng.root_stats()
+    assert sorted(rn.tolist()) == [npo] * 3 + [int(visits[0][mv]) + npo] and sorted(rn0.tolist()) == [0] * 3 + [int(visits[0][mv])]
+    eng.close()
+
+
+def test_peaked_prior_over_consecutive_moves(az, oracle):
+    """A prior that puts 15/16 on one move, followed for a whole game: the root keeps almost all
+    earlier visits (ten times n_playout after a dozen moves) and the default arena must cope."""
+    n, k, npo = 6, 4, 64
+    S = n * n
+
+    def policy(b):
+        low = min(b.avail[i] for i in range(b.n_avail)) if b.n_avail else -1
+        return [0.9375 if c == low else 0.0009765625 for c in range(S)], 0.0
+    eng = az.SelfPlayEngine(n, k, npo, 2, prior_mode=az.PRIOR_PEAKED)
+    eng.reset_games()
+    plies = _forced_line(az, oracle, eng, policy, n, k, npo, 30, (0, 1))
+    assert plies >= 12 and eng.arena_stats()[1] == 0
+    eng.close()
+    # with n_in_row below 3 a line can be complete before the reference's n_in_row + 2 stone
+    # threshold lets it count (game.py:136-137), so it need not contain the last stone
+    eng = az.SelfPlayEngine(n, 2, 40, 1, prior_mode=az.PRIOR_HASH)
+    eng.reset_games()
+    ob = oracle.OracleBoard(n, n, 2)
+    ob.init_board()
+    t = oracle.OracleMCTS("hash", c_puct=5, n_playout=40)
+    eng.search()
+    visits, q, _, rn = eng.root_stats()
+    acts, ovis, oq, _, _ = t.get_move_probs(ob, temp=1.0)
+    assert np.array_equal(visits[0][acts], ovis) and np.array_equal(q[0][acts], oq)
     eng.close()
 
 

@@ -11,7 +11,7 @@ G = helpers.GOLDEN
 
 
 def load(name):
-    return np.load(os.path.join(G, name), allow_pickle=True)
+    return helpers.load_golden(name)
 
 
 def test_rules_replay(oracle):
@@ -95,7 +95,7 @@ def test_tree_fixtures_bit_exact(oracle):
 
 def test_rng_matches_numpy_and_fixture(oracle):
     d = load("g5_rng.npz")
-    for key in d.files:
+    for key in d:
         seed = int(key.split("_")[1])
         r = oracle.OracleRng(seed)
         rs = np.random.RandomState(seed)

@@ -234,12 +234,11 @@ def gen_tree():
                 a2 = v2 = np.zeros(0, np.int32)
                 q2 = p2 = np.zeros(0)
                 root_n_after = root_n_before
-            cases.append(dict(n=n, k=k, prefix=prefix, cb=cbn, c_puct=c_puct, n_playout=npo,
+            cases.append(dict(n=n, k=k, prefix=np.asarray(prefix, dtype=np.int32), cb=cbn, c_puct=c_puct, n_playout=npo,
                               acts=a1, visits=v1, q=q1, p=p1, probs=np.array(probs),
                               probs_t=probs_t, move=mv, root_n_before=root_n_before,
                               root_n_after=root_n_after, acts2=a2, visits2=v2, q2=q2, p2=p2))
-    np.savez_compressed(os.path.join(OUT, "g2_tree.npz"),
-                        cases=np.array(cases, dtype=object))
+    np.savez_compressed(os.path.join(OUT, "g2_tree.npz"), **helpers.pack_records("cases", cases))
     print("g2_tree: %d cases" % len(cases))
 
 
@@ -321,7 +320,7 @@ def gen_games(net_params_6):
     g["cb"] = "numpy_net_f32"
     games.append(g)
     print("  game 6x6 numpy net: %d plies winner %d" % (len(g["moves"]), g["winner"]))
-    np.savez_compressed(os.path.join(OUT, "g3_games.npz"), games=np.array(games, dtype=object))
+    np.savez_compressed(os.path.join(OUT, "g3_games.npz"), **helpers.pack_records("games", games))
     print("g3_games: %d games" % len(games))
 
 
@@ -419,7 +418,7 @@ def gen_net_game8():
     g["param_seed"] = 115
     games.append(g)
     print("g7_net8: 15x15 %d plies winner %d" % (len(g["moves"]), g["winner"]))
-    np.savez_compressed(os.path.join(OUT, "g7_net8.npz"), games=np.array(games, dtype=object))
+    np.savez_compressed(os.path.join(OUT, "g7_net8.npz"), **helpers.pack_records("games", games))
 
 
 # ---------------------------------------------------------------- G6 augmentation
@@ -569,7 +568,7 @@ def gen_pure():
                           seed=seed, moves=np.array(log, dtype=np.int32), winner=int(w),
                           next_double=float(np.random.random_sample())))
         print("  az vs pure %dx%d start %d: %d plies winner %d" % (n, n, sp, len(log), w))
-    np.savez_compressed(os.path.join(OUT, "g8_pure.npz"), cases=np.array(cases, dtype=object), games=np.array(games, dtype=object))
+    np.savez_compressed(os.path.join(OUT, "g8_pure.npz"), **helpers.pack_records("cases", cases), **helpers.pack_records("games", games))
     print("g8_pure written: %d cases, %d games" % (len(cases), len(games)))
 
 
