@@ -12,7 +12,7 @@ LAYOUT_TORCH, LAYOUT_THEANO = 0, 1
 CNN_F16X3, CNN_F32 = 0, 1
 
 ERROR_NAMES = {-1: "AZG_EINVAL", -2: "AZG_EHIP", -3: "AZG_ENOWEIGHTS", -4: "AZG_EARENA",
-               -5: "AZG_ESTATE", -6: "AZG_EMOVE"}
+               -5: "AZG_ESTATE", -6: "AZG_EMOVE", -7: "AZG_ERANGE"}
 
 # every symbol include/azgomoku.h declares
 SYMBOLS = ["azg_create", "azg_destroy", "azg_last_error", "azg_set_weights", "azg_reset_games",
@@ -20,7 +20,7 @@ SYMBOLS = ["azg_create", "azg_destroy", "azg_last_error", "azg_set_weights", "az
            "azg_advance", "azg_update_with_move", "azg_status", "azg_states",
            "azg_drain_samples", "azg_eval_batch", "azg_board_step_batch", "azg_profile",
            "azg_stream", "azg_selfplay_begin", "azg_selfplay_step", "azg_selfplay_fetch",
-           "azg_selfplay_end", "azg_equi_data", "azg_pure_search", "azg_host_timing", "azg_arena_stats",
+           "azg_selfplay_end", "azg_equi_data", "azg_pure_search", "azg_host_timing", "azg_arena_stats", "azg_selfplay_fetch_packed", "azg_unpack_states", "azg_playout_begin", "azg_playout_end",
            "azg_board_step_batch_static"]
 
 
@@ -95,6 +95,11 @@ def load():
     L.azg_selfplay_begin.argtypes = [vp, C.c_double, C.c_uint32, C.c_int64, C.c_int64, C.c_int64]
     L.azg_selfplay_step.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.azg_selfplay_fetch.argtypes = [vp, vp, vp, vp, vp, vp]
+    L.azg_selfplay_fetch_packed.argtypes = [vp, vp, vp, vp, vp, vp, vp]
+    L.azg_unpack_states.argtypes = [vp, C.c_int, vp, vp, vp, vp]
+    ip = C.POINTER(C.c_int)
+    L.azg_playout_begin.argtypes = [vp, C.c_int, u64p, u64p, ip, ip, ip, ip]
+    L.azg_playout_end.argtypes = [vp, C.c_int, vp, C.c_double]
     L.azg_selfplay_end.argtypes = [vp, C.POINTER(C.c_int)]
     L.azg_equi_data.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, vp]
     L.azg_drain_samples.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, C.POINTER(C.c_int)]

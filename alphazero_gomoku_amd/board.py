@@ -49,6 +49,24 @@ class Board(object):
         self.last_move = -1
         self._stones = [0, 0]
 
+    @classmethod
+    def from_stones(cls, width, height, n_in_row, stones1, stones2, last_move, current_player):
+        """The board object a policy_value_fn sees for a position given as two stone sets
+        (Python ints, bit m = cell m): states, availables, last_move and current_player as
+        Board.do_move would have left them."""
+        b = cls(width=width, height=height, n_in_row=n_in_row)
+        b._stones = [int(stones1), int(stones2)]
+        b.states = {}
+        for m in range(width * height):
+            if (stones1 >> m) & 1:
+                b.states[m] = 1
+            elif (stones2 >> m) & 1:
+                b.states[m] = 2
+        b.availables = [m for m in range(width * height) if m not in b.states]
+        b.last_move = last_move
+        b.current_player = current_player
+        return b
+
     # game.py:70-90
     def move_to_location(self, move):
         return [move // self.width, move % self.width]

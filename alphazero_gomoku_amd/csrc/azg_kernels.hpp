@@ -147,7 +147,11 @@ __device__ __forceinline__ void search_body(DevState st)
             } else if (MODE == 0) {
                 const float *probs = smem + G::LG_OFF + wave * G::S;
                 wave_expand(st, tv, gl, d, g, lane, [=](int c) { return probs[c]; });
-                v = (double)smem[G::VAL_OFF + wave];
+                const float vf = smem[G::VAL_OFF + wave];
+                // an activation beyond the half-precision range makes its high half infinite, the
+                // next layer then forms inf - inf: a NaN that reaches every output of the position
+                if (F16 && !(vf == vf) && lane == 0) st.err[g] |= 4;
+                v = (double)vf;
             } else if (MODE == 1) {
                 const float p = 1.0f / (float)(st.S - d.ply);
                 wave_expand(st, tv, gl, d, g, lane, [=](int) { return p; });
@@ -201,11 +205,68 @@ AZG_CAPPED_SEARCH_KERNEL(search_kernel_f16_7x7, 7, 2)
 AZG_CAPPED_SEARCH_KERNEL(search_kernel_f16_8x8, 8, 2)
 #endif
 
+// ---------------------------------------------------------------- one playout, evaluated by the host
+// MCTS._playout (mcts_alphaZero.py:113-148) split at the policy call (:132), for a caller whose
+// policy_value_fn is arbitrary host code: playout_select_kernel descends to a leaf and parks the
+// playout (path, leaf position) in `park`; the host evaluates the leaf; playout_finish_kernel
+// expands with the host's priors (float32 by cell) and backs the value up.  One wave, one slot.
+struct LeafInfo {                      // what the host needs to build the leaf position
+    unsigned long long stones[2][MAXW];
+    int ply, last_move, current_player, term;
+};
+
+__global__ __launch_bounds__(64) void playout_select_kernel(DevState st, int g, GameLds *park, LeafInfo *info)
+{
+    __shared__ GameLds s_gl;
+    GameLds *gl = &s_gl;
+    const int lane = threadIdx.x;
+    if (lane < 2 * MAXW) ((u64 *)gl->root_bb)[lane] = st.bb[(size_t)g * 2 * MAXW + lane];
+    if (lane == 0) {
+        gl->live = 1; gl->gid = g; gl->need_eval = 0; gl->term = 0;
+        gl->root_ply = st.ply[g]; gl->root_last = st.last_move[g]; gl->first_player = st.first_player[g];
+        gl->arena = st.cur[g]; gl->used = st.used[g]; gl->big = st.big_of[g]; gl->cap = arena_cap(st, g);
+        gl->root_act = meta_act(tree_view(st, g, st.cur[g]).meta[0]);
+    }
+    wave_sync();
+    const TreeView tv = tree_view(st, g, gl->arena, gl->big);
+    const Descent d = wave_select<GameLds, false, MAXS / WAVE>(st, tv, gl, lane);
+    const int term = wave_game_end(gl->leaf_bb, st.N, st.S, st.n_in_row, d.ply, lane);
+    if (lane == 0) { gl->term = term; gl->need_eval = term == 0; }
+    wave_sync();
+    for (int i = lane; i < (int)(sizeof(GameLds) / 4); i += WAVE) ((int *)park)[i] = ((const int *)gl)[i];
+    if (lane < 2 * MAXW) ((u64 *)info->stones)[lane] = ((const u64 *)gl->leaf_bb)[lane];
+    if (lane == 0) {
+        info->ply = d.ply; info->last_move = d.last;
+        info->current_player = player_at(gl->first_player, d.ply);
+        info->term = term;
+    }
+}
+
+__global__ __launch_bounds__(64) void playout_finish_kernel(DevState st, int g, const GameLds *park, const float *priors,
+                                                            double value)
+{
+    __shared__ GameLds s_gl;
+    GameLds *gl = &s_gl;
+    const int lane = threadIdx.x;
+    for (int i = lane; i < (int)(sizeof(GameLds) / 4); i += WAVE) ((int *)gl)[i] = ((const int *)park)[i];
+    wave_sync();
+    Descent d;
+    d.leaf = gl->leaf; d.depth = gl->depth; d.ply = gl->leaf_ply; d.last = gl->leaf_last;
+    const TreeView tv = tree_view(st, g, gl->arena, gl->big);
+    const int term = gl->term;
+    double v = value;
+    if (term) v = term == 3 ? 0.0 : (term == player_at(gl->first_player, d.ply) ? 1.0 : -1.0);   // mcts_alphaZero.py:139-145
+    else wave_expand(st, tv, gl, d, g, lane, [=](int c) { return priors[c]; });
+    wave_backup(tv, gl, d.depth, v, lane);
+    wave_sync();
+    if (lane == 0) st.used[g] = gl->used;
+}
+
 // ---------------------------------------------------------------- eval_batch
 // PolicyValueNet.policy_value (policy_value_net_pytorch.py:80-94) on n states.
 template <int N, int T, bool F16>
 __global__ __launch_bounds__(256) void eval_kernel(NetWeights nw, const float *states, int n,
-                                                   float *probs, float *values)
+                                                   float *probs, float *values, int *bad)
 {
     using G = typename GeomPick<N, T, F16>::type;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -223,7 +284,11 @@ __global__ __launch_bounds__(256) void eval_kernel(NetWeights nw, const float *s
         const int leaf = idx / G::S;
         if (n0 + leaf < n) probs[(size_t)n0 * G::S + idx] = smem[G::LG_OFF + idx];
     }
-    if (threadIdx.x < T && n0 + threadIdx.x < n) values[n0 + threadIdx.x] = smem[G::VAL_OFF + threadIdx.x];
+    if (threadIdx.x < T && n0 + threadIdx.x < n) {
+        const float v = smem[G::VAL_OFF + threadIdx.x];
+        values[n0 + threadIdx.x] = v;
+        if (F16 && !(v == v)) atomicOr(bad, 1);             // see search_body: activations out of half range
+    }
 }
 
 // ---------------------------------------------------------------- numpy-order sums
@@ -621,7 +686,7 @@ __global__ void states_kernel(DevState st, float *out)
 // bank | (winner + 1) << 8 and map_id[i] identify the finished game.
 __global__ void drain_kernel(DevState st, int n, const int *map_g, const int *map_t, const int *map_aux,
                              const long long *map_id, float *states, double *pi, float *z, long long *gid,
-                             int *ply_out)
+                             int *ply_out, u64 *stones_out, int *last_out)
 {
     const int i = blockIdx.x;
     if (i >= n) return;
@@ -640,11 +705,31 @@ __global__ void drain_kernel(DevState st, int n, const int *map_g, const int *ma
     if (pi)
         for (int idx = threadIdx.x; idx < S; idx += blockDim.x)
             pi[(size_t)i * S + idx] = st.s_pi[si * S + idx];
+    // the packed form of the state (what current_state is computed from): 2 x MAXW words + last move
+    if (stones_out && threadIdx.x < 2 * MAXW) stones_out[(size_t)i * 2 * MAXW + threadIdx.x] = st.s_bb[si * 2 * MAXW + threadIdx.x];
     if (threadIdx.x == 0) {
+        if (last_out) last_out[i] = last;
         const int w = map_aux ? (map_aux[i] >> 8) - 1 : (int)st.winner[g];
         if (z) z[i] = (w == -1) ? 0.0f : (w == cur ? 1.0f : -1.0f);
         if (gid) gid[i] = map_id ? map_id[i] : st.game_id[g];
         if (ply_out) ply_out[i] = ply;
+    }
+}
+
+// Board.current_state (game.py:92-116) of n packed positions (stones [n][2][MAXW], last move, ply;
+// the player who moves at even ply is `first_player`): float32 [n][4][N][N].  One block per position.
+__global__ void unpack_states_kernel(int N, int n, int first_player, const u64 *stones, const int *last, const int *ply,
+                                     float *out)
+{
+    const int i = blockIdx.x;
+    if (i >= n) return;
+    const int S = N * N;
+    const u64(*bb)[MAXW] = reinterpret_cast<const u64(*)[MAXW]>(stones + (size_t)i * 2 * MAXW);
+    const int p = ply[i], l = last[i];
+    const int cur = player_at(first_player, p);
+    for (int idx = threadIdx.x; idx < 4 * S; idx += blockDim.x) {
+        const int pl = idx / S, rem = idx - pl * S;
+        out[(size_t)i * 4 * S + idx] = plane_value(bb, N, p, l, cur, pl, rem / N, rem % N);
     }
 }
 

@@ -126,6 +126,7 @@ struct azg_handle {
     std::vector<void *> allocs;
     unsigned char *static_scratch = nullptr;     // this device's copy of the file-scope scratch array
     int *h_static_bad = nullptr;                 // pinned: illegal-move flag read back by the static entry point
+    int playout_parked = -1;                     // slot with a playout between azg_playout_begin and azg_playout_end
     bool have_weights = false;
     float *d_weights = nullptr;
     // host mirrors, refreshed after every state-changing call
@@ -157,14 +158,15 @@ struct azg_handle {
         int par = 0;                             // parity of the sample set being produced
         int pend_n = 0, pend_games = 0;          // enqueued in the last step, complete by the next one
         int ready_n = 0, ready_games = 0, ready_par = 0;
+        bool fetched = true;                     // the ready samples were fetched (or there are none)
         int *h_map = nullptr;                    // pinned: per parity [3][B*S] slot | sample | aux
         long long *h_ids = nullptr;              // pinned: per parity [B*S]
     } sp;
     double *d_noise = nullptr, *d_u = nullptr, *d_pi = nullptr;
     int *d_moves = nullptr, *d_given = nullptr;
     // grow-on-demand device scratch
-    void *scratch[32] = {nullptr};
-    size_t scratch_sz[32] = {0};
+    void *scratch[48] = {nullptr};
+    size_t scratch_sz[48] = {0};
     // profiling
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
     size_t ev_pending = 0;
@@ -200,6 +202,17 @@ static int dev_alloc(azg_handle *h, T **p, size_t count, bool zero = true)
     if (zero) HIPCHK(h, hipMemsetAsync(q, 0, std::max<size_t>(count, 1) * sizeof(T), h->stream));
     *p = reinterpret_cast<T *>(q);
     return AZG_OK;
+}
+
+// true when p points into device memory (then a kernel can use it without staging)
+static bool is_device_ptr(const void *p)
+{
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+        (void)hipGetLastError();                              // plain host memory: not an error
+        return false;
+    }
+    return a.type == hipMemoryTypeDevice;
 }
 
 static int scratch_get(azg_handle *h, int slot, size_t bytes, void **out)
@@ -264,7 +277,7 @@ static bool pick_search(int N, int mode, int cnn_mode, SearchLaunch *out)
 }
 
 struct EvalLaunch {
-    void (*fn)(NetWeights, const float *, int, float *, float *);
+    void (*fn)(NetWeights, const float *, int, float *, float *, int *);
     int T;
     size_t lds;
 };
@@ -346,6 +359,8 @@ static int mirrors_unpack(azg_handle *h)
     for (int g = 0; g < B; g++) {
         if (h->h_err[g] & 1) return fail(h, AZG_EARENA, "slot %d: search tree outgrew its arena (arena_nodes=%d)", g, h->cfg.arena_nodes);
         if (h->h_err[g] & 2) return fail(h, AZG_EMOVE, "slot %d: illegal move", g);
+        if (h->h_err[g] & 4) return fail(h, AZG_ERANGE, "slot %d: an activation of the net left the half-precision range "
+                                         "(|x| > 65504) in the split-f16 convolutions; create the engine with AZG_CNN_F32", g);
     }
     return AZG_OK;
 }
@@ -391,7 +406,7 @@ static int create_impl(azg_handle *h)
     HIPCHK(h, hipSetDevice(c.device));
     HIPCHK(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     HIPCHK(h, static_scratch_ptr(c.device, &h->static_scratch));
-    HIPCHK(h, hipHostMalloc((void **)&h->h_static_bad, 16));
+    HIPCHK(h, hipHostMalloc((void **)&h->h_static_bad, 64));   // [0] board-step flag, bytes 16..31 arena counters, [12] CNN range flag
     DevState &st = h->st;
     st.N = N; st.S = S; st.NW = (S + 63) / 64; st.n_in_row = c.n_in_row; st.B = B;
     st.prior_mode = c.prior_mode; st.n_playout = c.n_playout; st.c_puct = c.c_puct;
@@ -949,7 +964,8 @@ extern "C" int azg_drain_samples(azg_handle *h, int max_samples, float *states, 
     HIPCHK(h, hipMemcpyAsync(dg, map_g.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemcpyAsync(dt, map_t.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, h->stream));
     hipLaunchKernelGGL(drain_kernel, dim3(n), dim3(64), 0, h->stream, h->st, n, (const int *)dg, (const int *)dt,
-                       (const int *)nullptr, (const long long *)nullptr, states ? (float *)ds : nullptr, pi ? (double *)dp : nullptr, (float *)dz, (long long *)di, (int *)dl);
+                       (const int *)nullptr, (const long long *)nullptr, states ? (float *)ds : nullptr, pi ? (double *)dp : nullptr, (float *)dz, (long long *)di, (int *)dl,
+                       (u64 *)nullptr, (int *)nullptr);
     HIPCHK(h, hipGetLastError());
     if (states) HIPCHK(h, hipMemcpyAsync(states, ds, (size_t)n * 4 * S * sizeof(float), hipMemcpyDefault, h->stream));
     if (pi) HIPCHK(h, hipMemcpyAsync(pi, dp, (size_t)n * S * sizeof(double), hipMemcpyDefault, h->stream));
@@ -957,6 +973,52 @@ extern "C" int azg_drain_samples(azg_handle *h, int max_samples, float *states, 
     if (game_id) HIPCHK(h, hipMemcpyAsync(game_id, di, (size_t)n * sizeof(long long), hipMemcpyDefault, h->stream));
     if (ply) HIPCHK(h, hipMemcpyAsync(ply, dl, (size_t)n * sizeof(int), hipMemcpyDefault, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    return AZG_OK;
+}
+
+// ---------------------------------------------------------------- playouts evaluated by the caller
+extern "C" int azg_playout_begin(azg_handle *h, int slot, uint64_t stones1[4], uint64_t stones2[4], int *ply,
+                                 int *last_move, int *current_player, int *terminal)
+{
+    if (!h || !stones1 || !stones2 || !ply || !last_move || !current_player || !terminal) return fail(h, AZG_EINVAL, "null argument");
+    NOT_WHILE_PIPELINED(h);
+    if (slot < 0 || slot >= h->cfg.n_games) return fail(h, AZG_EINVAL, "slot %d out of range", slot);
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    if (!h->mirrors_fresh) { int rc = refresh_mirrors(h); if (rc) return rc; }
+    if (h->h_status[slot] != 0) return fail(h, AZG_ESTATE, "slot %d holds no live game", slot);
+    void *park, *info;
+    int rc;
+    if ((rc = scratch_get(h, 41, sizeof(GameLds), &park))) return rc;
+    if ((rc = scratch_get(h, 42, sizeof(LeafInfo), &info))) return rc;
+    hipLaunchKernelGGL(playout_select_kernel, dim3(1), dim3(64), 0, h->stream, h->st, slot, (GameLds *)park, (LeafInfo *)info);
+    HIPCHK(h, hipGetLastError());
+    LeafInfo li;
+    HIPCHK(h, hipMemcpyAsync(&li, info, sizeof(li), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    for (int i = 0; i < MAXW; i++) { stones1[i] = li.stones[0][i]; stones2[i] = li.stones[1][i]; }
+    *ply = li.ply; *last_move = li.last_move; *current_player = li.current_player;
+    *terminal = li.term == 0 ? 0 : (li.term == 3 ? -1 : li.term);
+    h->playout_parked = slot;
+    return AZG_OK;
+}
+
+extern "C" int azg_playout_end(azg_handle *h, int slot, const float *priors, double value)
+{
+    if (!h) return AZG_EINVAL;
+    NOT_WHILE_PIPELINED(h);
+    if (h->playout_parked != slot || slot < 0) return fail(h, AZG_ESTATE, "azg_playout_begin has not been called for slot %d", slot);
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    const int S = h->st.S;
+    void *dp;
+    int rc;
+    if ((rc = scratch_get(h, 43, (size_t)MAXS * sizeof(float), &dp))) return rc;
+    if (priors) HIPCHK(h, hipMemcpyAsync(dp, priors, (size_t)S * sizeof(float), hipMemcpyDefault, h->stream));
+    else HIPCHK(h, hipMemsetAsync(dp, 0, (size_t)S * sizeof(float), h->stream));
+    hipLaunchKernelGGL(playout_finish_kernel, dim3(1), dim3(64), 0, h->stream, h->st, slot, (const GameLds *)h->scratch[41],
+                       (const float *)dp, value);
+    HIPCHK(h, hipGetLastError());
+    h->playout_parked = -1;
+    h->mirrors_fresh = false;
     return AZG_OK;
 }
 
@@ -1001,18 +1063,29 @@ extern "C" int azg_eval_batch(azg_handle *h, const float *states, int n, float *
     EvalLaunch el;
     if (!pick_eval(h->cfg.board_n, h->cfg.cnn_mode, &el)) return fail(h, AZG_EINVAL, "no CNN kernel is built for board_n=%d", h->cfg.board_n);
     const int S = h->st.S;
-    void *ds, *dp, *dv;
+    void *ds = const_cast<float *>(states), *dp = probs, *dv = values;
     int rc;
-    if ((rc = scratch_get(h, 2, (size_t)n * 4 * S * sizeof(float), &ds))) return rc;
-    if ((rc = scratch_get(h, 3, (size_t)n * S * sizeof(float), &dp))) return rc;
-    if ((rc = scratch_get(h, 4, (size_t)n * sizeof(float), &dv))) return rc;
-    HIPCHK(h, hipMemcpyAsync(ds, states, (size_t)n * 4 * S * sizeof(float), hipMemcpyDefault, h->stream));
+    // device pointers are used in place, host pointers staged
+    const bool st_dev = is_device_ptr(states), p_dev = probs && is_device_ptr(probs), v_dev = values && is_device_ptr(values);
+    if (!st_dev) {
+        if ((rc = scratch_get(h, 2, (size_t)n * 4 * S * sizeof(float), &ds))) return rc;
+        HIPCHK(h, hipMemcpyAsync(ds, states, (size_t)n * 4 * S * sizeof(float), hipMemcpyDefault, h->stream));
+    }
+    if (!p_dev && (rc = scratch_get(h, 3, (size_t)n * S * sizeof(float), &dp))) return rc;
+    if (!v_dev && (rc = scratch_get(h, 4, (size_t)n * sizeof(float), &dv))) return rc;
+    void *dbad;
+    if ((rc = scratch_get(h, 40, 16, &dbad))) return rc;
+    HIPCHK(h, hipMemsetAsync(dbad, 0, 16, h->stream));
     hipLaunchKernelGGL(el.fn, dim3((n + el.T - 1) / el.T), dim3(256), el.lds, h->stream, h->st.net,
-                       (const float *)ds, n, (float *)dp, (float *)dv);
+                       (const float *)ds, n, (float *)dp, (float *)dv, (int *)dbad);
     HIPCHK(h, hipGetLastError());
-    if (probs) HIPCHK(h, hipMemcpyAsync(probs, dp, (size_t)n * S * sizeof(float), hipMemcpyDefault, h->stream));
-    if (values) HIPCHK(h, hipMemcpyAsync(values, dv, (size_t)n * sizeof(float), hipMemcpyDefault, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->h_static_bad + 12, dbad, 4, hipMemcpyDeviceToHost, h->stream));
+    if (probs && !p_dev) HIPCHK(h, hipMemcpyAsync(probs, dp, (size_t)n * S * sizeof(float), hipMemcpyDefault, h->stream));
+    if (values && !v_dev) HIPCHK(h, hipMemcpyAsync(values, dv, (size_t)n * sizeof(float), hipMemcpyDefault, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (h->h_static_bad[12])
+        return fail(h, AZG_ERANGE, "an activation of the net left the half-precision range (|x| > 65504) in the split-f16 "
+                    "convolutions; create the engine with AZG_CNN_F32");
     return AZG_OK;
 }
 
@@ -1135,6 +1208,7 @@ extern "C" int azg_selfplay_begin(azg_handle *h, double temp, uint32_t seed0, in
     if (!sp.h_ids) HIPCHK(h, hipHostMalloc((void **)&sp.h_ids, (size_t)2 * B * S * sizeof(long long)));
     sp.temp = temp; sp.seed0 = seed0; sp.first = first_id; sp.stride = stride; sp.total = total;
     sp.par = 0; sp.pend_n = sp.pend_games = sp.ready_n = sp.ready_games = 0;
+    sp.fetched = true;
     // slots 0..B-1 start games k = 0..B-1 of this engine's sequence
     std::vector<uint8_t> mask(B, 0);
     std::vector<uint32_t> seeds(B, 0);
@@ -1191,13 +1265,16 @@ static int sp_enqueue_drain(azg_handle *h)
     if ((rc = scratch_get(h, base + 6, (size_t)n * sizeof(float), &dz))) return rc;
     if ((rc = scratch_get(h, base + 7, (size_t)n * sizeof(long long), &dgid))) return rc;
     if ((rc = scratch_get(h, base + 8, (size_t)n * sizeof(int), &dply))) return rc;
+    void *dst, *dla;
+    if ((rc = scratch_get(h, 32 + sp.par * 2, (size_t)n * 2 * MAXW * sizeof(u64), &dst))) return rc;
+    if ((rc = scratch_get(h, 33 + sp.par * 2, (size_t)n * sizeof(int), &dla))) return rc;
     HIPCHK(h, hipMemcpyAsync(dg, mg, (size_t)n * sizeof(int), hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemcpyAsync(dt, mt, (size_t)n * sizeof(int), hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemcpyAsync(da, ma, (size_t)n * sizeof(int), hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemcpyAsync(di, mi, (size_t)n * sizeof(long long), hipMemcpyHostToDevice, h->stream));
     hipLaunchKernelGGL(drain_kernel, dim3(n), dim3(64), 0, h->stream, h->st, n, (const int *)dg, (const int *)dt,
                        (const int *)da, (const long long *)di, (float *)ds, (double *)dp, (float *)dz,
-                       (long long *)dgid, (int *)dply);
+                       (long long *)dgid, (int *)dply, (u64 *)dst, (int *)dla);
     HIPCHK(h, hipGetLastError());
     return AZG_OK;
 }
@@ -1209,6 +1286,9 @@ extern "C" int azg_selfplay_step(azg_handle *h, int *games_finished, int *sample
     HIPCHK(h, hipSetDevice(h->cfg.device));
     auto &sp = h->sp;
     const int B = h->cfg.n_games, S = h->st.S;
+    if (!sp.fetched)
+        return fail(h, AZG_ESTATE, "%d samples made ready by the previous step were not fetched: call azg_selfplay_fetch "
+                    "(null pointers discard them) before the next step", sp.ready_n);
     make_noise(h);                                  // while the search enqueued last time runs
     // the upload goes over the copy stream, i.e. also while that search runs (the previous
     // advance, the last reader of these buffers, completed before the last step returned)
@@ -1237,6 +1317,7 @@ extern "C" int azg_selfplay_step(azg_handle *h, int *games_finished, int *sample
     }
     if ((rc = sp_enqueue_drain(h))) return rc;
     sp.par ^= 1;
+    sp.fetched = sp.ready_n == 0;
     if (games_finished) *games_finished = fin;
     if (samples_ready) *samples_ready = sp.ready_n;
     return AZG_OK;
@@ -1248,6 +1329,7 @@ extern "C" int azg_selfplay_fetch(azg_handle *h, float *states, double *pi, floa
     HIPCHK(h, hipSetDevice(h->cfg.device));
     auto &sp = h->sp;
     const int n = sp.ready_n, S = h->st.S;
+    sp.fetched = true;
     if (n == 0) return AZG_OK;
     const int base = 8 + sp.ready_par * 9;
     hipStream_t cs = sp.copy_stream;
@@ -1256,6 +1338,52 @@ extern "C" int azg_selfplay_fetch(azg_handle *h, float *states, double *pi, floa
     if (z) HIPCHK(h, hipMemcpyAsync(z, h->scratch[base + 6], (size_t)n * sizeof(float), hipMemcpyDefault, cs));
     if (game_id) HIPCHK(h, hipMemcpyAsync(game_id, h->scratch[base + 7], (size_t)n * sizeof(long long), hipMemcpyDefault, cs));
     if (ply) HIPCHK(h, hipMemcpyAsync(ply, h->scratch[base + 8], (size_t)n * sizeof(int), hipMemcpyDefault, cs));
+    HIPCHK(h, hipStreamSynchronize(cs));
+    return AZG_OK;
+}
+
+extern "C" int azg_selfplay_fetch_packed(azg_handle *h, uint64_t *stones, int32_t *last_move, double *pi, float *z,
+                                         int64_t *game_id, int32_t *ply)
+{
+    if (!h) return AZG_EINVAL;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    auto &sp = h->sp;
+    const int n = sp.ready_n, S = h->st.S;
+    sp.fetched = true;
+    if (n == 0) return AZG_OK;
+    const int base = 8 + sp.ready_par * 9;
+    hipStream_t cs = sp.copy_stream;
+    if (stones) HIPCHK(h, hipMemcpyAsync(stones, h->scratch[32 + sp.ready_par * 2], (size_t)n * 2 * MAXW * sizeof(u64), hipMemcpyDefault, cs));
+    if (last_move) HIPCHK(h, hipMemcpyAsync(last_move, h->scratch[33 + sp.ready_par * 2], (size_t)n * sizeof(int), hipMemcpyDefault, cs));
+    if (pi) HIPCHK(h, hipMemcpyAsync(pi, h->scratch[base + 5], (size_t)n * S * sizeof(double), hipMemcpyDefault, cs));
+    if (z) HIPCHK(h, hipMemcpyAsync(z, h->scratch[base + 6], (size_t)n * sizeof(float), hipMemcpyDefault, cs));
+    if (game_id) HIPCHK(h, hipMemcpyAsync(game_id, h->scratch[base + 7], (size_t)n * sizeof(long long), hipMemcpyDefault, cs));
+    if (ply) HIPCHK(h, hipMemcpyAsync(ply, h->scratch[base + 8], (size_t)n * sizeof(int), hipMemcpyDefault, cs));
+    HIPCHK(h, hipStreamSynchronize(cs));
+    return AZG_OK;
+}
+
+extern "C" int azg_unpack_states(azg_handle *h, int n, const uint64_t *stones, const int32_t *last_move, const int32_t *ply,
+                                 float *states)
+{
+    if (!h || !stones || !last_move || !ply || !states || n < 0) return fail(h, AZG_EINVAL, "bad argument");
+    if (n == 0) return AZG_OK;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    const int S = h->st.S;
+    hipStream_t cs = (h->sp.active && h->sp.copy_stream) ? h->sp.copy_stream : h->stream;   // never behind a search in flight
+    void *ds, *dl, *dp, *os;
+    int rc;
+    if ((rc = scratch_get(h, 36, (size_t)n * 2 * MAXW * sizeof(u64), &ds))) return rc;
+    if ((rc = scratch_get(h, 37, (size_t)n * sizeof(int), &dl))) return rc;
+    if ((rc = scratch_get(h, 38, (size_t)n * sizeof(int), &dp))) return rc;
+    if ((rc = scratch_get(h, 39, (size_t)n * 4 * S * sizeof(float), &os))) return rc;
+    HIPCHK(h, hipMemcpyAsync(ds, stones, (size_t)n * 2 * MAXW * sizeof(u64), hipMemcpyDefault, cs));
+    HIPCHK(h, hipMemcpyAsync(dl, last_move, (size_t)n * sizeof(int), hipMemcpyDefault, cs));
+    HIPCHK(h, hipMemcpyAsync(dp, ply, (size_t)n * sizeof(int), hipMemcpyDefault, cs));
+    hipLaunchKernelGGL(unpack_states_kernel, dim3(n), dim3(256), 0, cs, h->st.N, n, 1, (const u64 *)ds, (const int *)dl,
+                       (const int *)dp, (float *)os);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipMemcpyAsync(states, os, (size_t)n * 4 * S * sizeof(float), hipMemcpyDefault, cs));
     HIPCHK(h, hipStreamSynchronize(cs));
     return AZG_OK;
 }
@@ -1281,25 +1409,36 @@ extern "C" int azg_equi_data(azg_handle *h, int n, const float *states, const do
     if (n == 0) return AZG_OK;
     HIPCHK(h, hipSetDevice(h->cfg.device));
     const int S = h->st.S;
-    // staging on the copy-free side: inputs and outputs may be host or device memory
-    void *ds, *dp, *dz, *os, *op, *oz;
+    // inputs and outputs may be host or device memory: device pointers are used in place, host
+    // pointers staged.  While self-play is pipelined the work goes to the copy stream, so that it
+    // never queues behind the search in flight.
+    void *ds = const_cast<float *>(states), *dp = const_cast<double *>(pi), *dz = const_cast<float *>(z);
+    void *os = states_out, *op = pi_out, *oz = z_out;
     int rc;
-    hipStream_t cs = h->stream;
-    if ((rc = scratch_get(h, 26, (size_t)n * 4 * S * sizeof(float), &ds))) return rc;
-    if ((rc = scratch_get(h, 27, (size_t)n * S * sizeof(double), &dp))) return rc;
-    if ((rc = scratch_get(h, 28, (size_t)n * sizeof(float), &dz))) return rc;
-    if ((rc = scratch_get(h, 29, (size_t)8 * n * 4 * S * sizeof(float), &os))) return rc;
-    if ((rc = scratch_get(h, 30, (size_t)8 * n * S * sizeof(double), &op))) return rc;
-    if ((rc = scratch_get(h, 31, (size_t)8 * n * sizeof(float), &oz))) return rc;
-    HIPCHK(h, hipMemcpyAsync(ds, states, (size_t)n * 4 * S * sizeof(float), hipMemcpyDefault, cs));
-    HIPCHK(h, hipMemcpyAsync(dp, pi, (size_t)n * S * sizeof(double), hipMemcpyDefault, cs));
-    HIPCHK(h, hipMemcpyAsync(dz, z, (size_t)n * sizeof(float), hipMemcpyDefault, cs));
+    hipStream_t cs = (h->sp.active && h->sp.copy_stream) ? h->sp.copy_stream : h->stream;
+    const bool in_dev = is_device_ptr(states) && is_device_ptr(pi) && is_device_ptr(z);
+    const bool out_dev = is_device_ptr(states_out) && is_device_ptr(pi_out) && is_device_ptr(z_out);
+    if (!in_dev) {
+        if ((rc = scratch_get(h, 26, (size_t)n * 4 * S * sizeof(float), &ds))) return rc;
+        if ((rc = scratch_get(h, 27, (size_t)n * S * sizeof(double), &dp))) return rc;
+        if ((rc = scratch_get(h, 28, (size_t)n * sizeof(float), &dz))) return rc;
+        HIPCHK(h, hipMemcpyAsync(ds, states, (size_t)n * 4 * S * sizeof(float), hipMemcpyDefault, cs));
+        HIPCHK(h, hipMemcpyAsync(dp, pi, (size_t)n * S * sizeof(double), hipMemcpyDefault, cs));
+        HIPCHK(h, hipMemcpyAsync(dz, z, (size_t)n * sizeof(float), hipMemcpyDefault, cs));
+    }
+    if (!out_dev) {
+        if ((rc = scratch_get(h, 29, (size_t)8 * n * 4 * S * sizeof(float), &os))) return rc;
+        if ((rc = scratch_get(h, 30, (size_t)8 * n * S * sizeof(double), &op))) return rc;
+        if ((rc = scratch_get(h, 31, (size_t)8 * n * sizeof(float), &oz))) return rc;
+    }
     hipLaunchKernelGGL(equi_kernel, dim3(8 * n), dim3(256), 0, cs, h->st.N, n, (const float *)ds, (const double *)dp,
                        (const float *)dz, (float *)os, (double *)op, (float *)oz);
     HIPCHK(h, hipGetLastError());
-    HIPCHK(h, hipMemcpyAsync(states_out, os, (size_t)8 * n * 4 * S * sizeof(float), hipMemcpyDefault, cs));
-    HIPCHK(h, hipMemcpyAsync(pi_out, op, (size_t)8 * n * S * sizeof(double), hipMemcpyDefault, cs));
-    HIPCHK(h, hipMemcpyAsync(z_out, oz, (size_t)8 * n * sizeof(float), hipMemcpyDefault, cs));
+    if (!out_dev) {
+        HIPCHK(h, hipMemcpyAsync(states_out, os, (size_t)8 * n * 4 * S * sizeof(float), hipMemcpyDefault, cs));
+        HIPCHK(h, hipMemcpyAsync(pi_out, op, (size_t)8 * n * S * sizeof(double), hipMemcpyDefault, cs));
+        HIPCHK(h, hipMemcpyAsync(z_out, oz, (size_t)8 * n * sizeof(float), hipMemcpyDefault, cs));
+    }
     HIPCHK(h, hipStreamSynchronize(cs));
     return AZG_OK;
 }
@@ -1323,9 +1462,9 @@ extern "C" int azg_arena_stats(azg_handle *h, int64_t *moved_to_large, int64_t *
     unsigned long long v[2] = {0, 0};
     // on the copy stream when self-play is pipelined: a search in flight must not be waited for
     hipStream_t s = (h->sp.active && h->sp.copy_stream) ? h->sp.copy_stream : h->stream;
-    HIPCHK(h, hipMemcpyAsync(h->h_static_bad, h->st.arena_stats, sizeof(v), hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipMemcpyAsync(h->h_static_bad + 4, h->st.arena_stats, sizeof(v), hipMemcpyDeviceToHost, s));
     HIPCHK(h, hipStreamSynchronize(s));
-    memcpy(v, h->h_static_bad, sizeof(v));
+    memcpy(v, h->h_static_bad + 4, sizeof(v));
     if (moved_to_large) *moved_to_large = (int64_t)v[0];
     if (trees_dropped) *trees_dropped = (int64_t)v[1];
     return AZG_OK;

@@ -41,6 +41,51 @@ def gather_samples(tensors, group=None):
     return out
 
 
+PACKED_FIELDS = (("stones", torch.int64, 8), ("last", torch.int32, 1), ("ply", torch.int32, 1),
+                 ("z", torch.float32, 1), ("game_id", torch.int64, 1))
+
+
+def pack_samples(t):
+    """Training tuples in their packed form -- stones int64 [n,2,4] (the two colours' bit sets),
+    last i32 [n], ply i32 [n], z f32 [n], game_id i64 [n], pi f64 [n,S] -- as ONE uint8 matrix
+    [n, 84 + 8*S]: a row is a whole tuple (596 bytes at 8x8 against 1.3 KB with float planes)."""
+    n = int(t["z"].shape[0])
+    cols = [t[name].to(dtype).contiguous().view(torch.uint8).reshape(n, -1) for name, dtype, _ in PACKED_FIELDS]
+    cols.append(t["pi"].to(torch.float64).contiguous().view(torch.uint8).reshape(n, -1))
+    return torch.cat(cols, dim=1)
+
+
+def unpack_samples(rows, n_cells):
+    """Inverse of pack_samples."""
+    n = int(rows.shape[0])
+    out, off = {}, 0
+    for name, dtype, count in PACKED_FIELDS:
+        width = count * torch.empty(0, dtype=dtype).element_size()
+        out[name] = rows[:, off:off + width].contiguous().view(dtype).reshape((n, 2, 4) if name == "stones" else (n,))
+        off += width
+    out["pi"] = rows[:, off:off + 8 * n_cells].contiguous().view(torch.float64).reshape(n, n_cells)
+    return out
+
+
+def gather_packed(t, n_cells, group=None):
+    """All ranks' training tuples, rank after rank, with two collectives in all: an all_gather of
+    the per-rank counts and ONE padded all_gather of the packed rows (pack_samples).  The feature
+    planes are not sent; the receiver rebuilds them from the stones (SelfPlayEngine.unpack_states)."""
+    world = dist.get_world_size(group)
+    rows = pack_samples(t)
+    n, dev = int(rows.shape[0]), rows.device
+    counts = torch.zeros(world, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(counts, torch.tensor([n], dtype=torch.int64, device=dev), group=group)
+    counts_h = counts.cpu().tolist()
+    nmax = max(counts_h)
+    pad = torch.zeros((nmax, rows.shape[1]), dtype=torch.uint8, device=dev)
+    pad[:n] = rows
+    buf = torch.empty((world * nmax, rows.shape[1]), dtype=torch.uint8, device=dev)
+    dist.all_gather_into_tensor(buf, pad, group=group)
+    buf = buf.view(world, nmax, rows.shape[1])
+    return unpack_samples(torch.cat([buf[r, :counts_h[r]] for r in range(world)], dim=0), n_cells)
+
+
 def broadcast_weights(net, src=0, group=None):
     """Replicate rank `src`'s parameters (476 KB at 8x8) after an optimiser step."""
     for t in net.param_tensors():

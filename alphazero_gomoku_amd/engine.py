@@ -87,6 +87,27 @@ class SelfPlayEngine:
     def search(self):
         self._chk(self.L.azg_search(self.h))
 
+    def playout_begin(self, slot=0):
+        """First half of one playout (select down to a leaf) -> (stones1, stones2, ply, last_move,
+        current_player, terminal): the two stone sets as Python ints (bit m = cell m), terminal
+        0 / 1 / 2 / -1 (game goes on, winner, tie)."""
+        s1, s2 = (C.c_uint64 * 4)(), (C.c_uint64 * 4)()
+        ply, last, cur, term = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        self._chk(self.L.azg_playout_begin(self.h, int(slot), s1, s2, C.byref(ply), C.byref(last), C.byref(cur),
+                                           C.byref(term)))
+        as_int = lambda w: sum(int(w[i]) << (64 * i) for i in range(4))
+        return as_int(s1), as_int(s2), ply.value, last.value, cur.value, term.value
+
+    def playout_end(self, priors, value, slot=0):
+        """Second half: expand the leaf with priors (float32 [S] by cell, None for a terminal leaf)
+        and back `value` up."""
+        if priors is None:
+            self._chk(self.L.azg_playout_end(self.h, int(slot), None, float(value)))
+            return
+        p = np.ascontiguousarray(priors, dtype=np.float32)
+        assert p.shape == (self.S,)
+        self._chk(self.L.azg_playout_end(self.h, int(slot), C.c_void_p(p.ctypes.data), float(value)))
+
     def pure_search(self, n_playout, mt_state):
         """The rollout opponent's move for every live slot (mcts_pure.py:214-231, 261-268).
         mt_state: uint32 [B, 625], per slot the 624 MT19937 key words and the position of
@@ -183,19 +204,29 @@ class SelfPlayEngine:
         self._chk(self.L.azg_selfplay_end(self.h, C.byref(ready)))
         return ready.value
 
-    def selfplay_fetch(self, n, device=False):
-        """The n ready samples as a dict of numpy arrays (or torch CUDA tensors with device=True)."""
+    def selfplay_fetch(self, n, device=False, packed=False):
+        """The n ready samples as a dict of numpy arrays (or torch CUDA tensors with device=True).
+        packed=True (device only): `stones` u64-as-int64 [n,2,4] and `last` i32 [n] instead of the
+        feature planes `states` (see unpack_states)."""
         if device:
             import torch
             dev = torch.device("cuda", self.device)
-            t = dict(states=torch.empty((n, 4, self.N, self.N), dtype=torch.float32, device=dev),
-                     pi=torch.empty((n, self.S), dtype=torch.float64, device=dev),
+            t = dict(pi=torch.empty((n, self.S), dtype=torch.float64, device=dev),
                      z=torch.empty(n, dtype=torch.float32, device=dev),
                      game_id=torch.empty(n, dtype=torch.int64, device=dev),
                      ply=torch.empty(n, dtype=torch.int32, device=dev))
+            if packed:
+                t["stones"] = torch.empty((n, 2, 4), dtype=torch.int64, device=dev)
+                t["last"] = torch.empty(n, dtype=torch.int32, device=dev)
+                keys = ("stones", "last", "pi", "z", "game_id", "ply")
+                fn = self.L.azg_selfplay_fetch_packed
+            else:
+                t["states"] = torch.empty((n, 4, self.N, self.N), dtype=torch.float32, device=dev)
+                keys = ("states", "pi", "z", "game_id", "ply")
+                fn = self.L.azg_selfplay_fetch
             if n:
-                self._chk(self.L.azg_selfplay_fetch(self.h, *[C.c_void_p(t[k].data_ptr())
-                                                             for k in ("states", "pi", "z", "game_id", "ply")]))
+                torch.cuda.current_stream(dev).synchronize()          # the buffers exist before the engine's stream writes them
+                self._chk(fn(self.h, *[C.c_void_p(t[k].data_ptr()) for k in keys]))
             return t
         t = dict(states=np.zeros((n, 4, self.N, self.N), dtype=np.float32), pi=np.zeros((n, self.S)),
                  z=np.zeros(n, dtype=np.float32), game_id=np.zeros(n, dtype=np.int64), ply=np.zeros(n, dtype=np.int32))
@@ -209,6 +240,33 @@ class SelfPlayEngine:
         probs = np.zeros((n, self.S), dtype=np.float32)
         vals = np.zeros(n, dtype=np.float32)
         self._chk(self.L.azg_eval_batch(self.h, _ptr(st), n, _ptr(probs), _ptr(vals)))
+        return probs, vals
+
+    def unpack_states(self, stones, last, ply):
+        """Board.current_state planes (torch CUDA f32 [n,4,N,N]) of packed self-play positions:
+        stones int64 [n,2,4] (bit sets of stone 1 / stone 2), last i32 [n], ply i32 [n]."""
+        import torch
+        n = int(ply.shape[0])
+        out = torch.empty((n, 4, self.N, self.N), dtype=torch.float32, device=stones.device)
+        if n:
+            torch.cuda.current_stream(stones.device).synchronize()
+            self._chk(self.L.azg_unpack_states(self.h, n, C.c_void_p(stones.contiguous().data_ptr()),
+                                               C.c_void_p(last.contiguous().data_ptr()), C.c_void_p(ply.contiguous().data_ptr()),
+                                               C.c_void_p(out.data_ptr())))
+        return out
+
+    def eval_batch_device(self, states):
+        """eval_batch on a torch CUDA float32 tensor [n,4,N,N] of the engine's device, results as
+        torch tensors on that device (no host copy, no staging)."""
+        import torch
+        st = states.contiguous()
+        n = int(st.shape[0])
+        probs = torch.empty((n, self.S), dtype=torch.float32, device=st.device)
+        vals = torch.empty(n, dtype=torch.float32, device=st.device)
+        if n:
+            torch.cuda.current_stream(st.device).synchronize()
+            self._chk(self.L.azg_eval_batch(self.h, C.c_void_p(st.data_ptr()), n, C.c_void_p(probs.data_ptr()),
+                                            C.c_void_p(vals.data_ptr())))
         return probs, vals
 
     def board_step_batch(self, stones, ply, last_move, moves, player, want_planes=True, static=False):
@@ -288,11 +346,12 @@ class SelfPlayRunner:
     played are the same either way; which slot plays which game may differ."""
 
     def __init__(self, engine, temp=1.0, seed0=0, first_game_id=0, game_id_stride=1, total=None,
-                 on_samples=None, device_samples=False, pipelined=False):
+                 on_samples=None, device_samples=False, pipelined=False, packed_samples=False):
         self.e, self.temp, self.seed0 = engine, float(temp), int(seed0)
         self.first, self.stride, self.total = int(first_game_id), int(game_id_stride), total
         self.on_samples, self.device_samples = on_samples, device_samples
         self.pipelined, self._running = bool(pipelined), False
+        self.packed_samples = bool(packed_samples)          # pipelined + device_samples only
         B = engine.B
         self.ids = np.zeros(B, dtype=np.int64)
         self.seeds = np.zeros(B, dtype=np.uint32)
@@ -329,7 +388,7 @@ class SelfPlayRunner:
         self.games_delivered += self._undelivered
         self._undelivered = 0
         if n:
-            out = self.e.selfplay_fetch(n, device=self.device_samples)
+            out = self.e.selfplay_fetch(n, device=self.device_samples, packed=self.packed_samples)
             self.plies_done += n
             if self.on_samples is not None:
                 self.on_samples(out)

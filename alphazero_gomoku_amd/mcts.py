@@ -20,26 +20,32 @@ def softmax(x):
 class MCTSPlayer(object):
     """AI player based on MCTS.
 
-    `policy_value_function` is what the reference passes: the bound method
-    PolicyValueNet.policy_value_fn (train.py:102-105).  The search cannot call back into
-    Python per playout, so the owner of that method supplies the weights; a
-    PolicyValueNet instance, or the strings 'uniform32' / 'hash' (exact synthetic
-    providers used by the parity tests), are accepted too.  Any other callable raises."""
+    `policy_value_function` is what the reference passes (train.py:102-105, human_play.py).
+    When it is the bound method PolicyValueNet.policy_value_fn of this package (or the net
+    itself), the whole search of a move runs in one GPU launch with the net's weights; the
+    strings 'uniform32' / 'hash' select the exact synthetic providers of the parity tests.  Any
+    OTHER callable -- the reference's contract policy_value_fn(board) -> (iterable of (action,
+    prob), value), mcts_alphaZero.py:98-103 -- is called once per playout: the GPU selects down
+    to a leaf, the host evaluates it, the GPU expands and backs up (priors are rounded to float32
+    and widened once, the convention of the whole engine)."""
 
     def __init__(self, policy_value_function, c_puct=5, n_playout=2000, is_selfplay=0, device=0):
         self._c_puct, self._n_playout = float(c_puct), int(n_playout)
         self._is_selfplay = is_selfplay
         self._device = device
         self._net = None
+        self._callback = None
         self._mode = _lib.PRIOR_NET
         owner = getattr(policy_value_function, "__self__", policy_value_function)
         if isinstance(policy_value_function, str):
             self._mode = {"uniform32": _lib.PRIOR_UNIFORM32, "hash": _lib.PRIOR_HASH}[policy_value_function]
         elif hasattr(owner, "sync_engine") and hasattr(owner, "param_tensors"):
             self._net = owner
+        elif callable(policy_value_function):
+            self._callback = policy_value_function
+            self._mode = _lib.PRIOR_UNIFORM32                 # placeholder: the fused search is not used
         else:
-            raise TypeError("MCTSPlayer needs PolicyValueNet.policy_value_fn (or the net itself): "
-                            "an arbitrary Python callback cannot be evaluated inside the GPU search")
+            raise TypeError("policy_value_function must be callable (or 'uniform32' / 'hash')")
         self._engine = None
         self._engine_key = None
         self._weights_version = -1
@@ -71,11 +77,30 @@ class MCTSPlayer(object):
         """MCTS.get_move_probs (mcts_alphaZero.py:154-181): (acts, probs)."""
         eng = self._get_engine(board)
         eng.set_position(0, board.states, board.last_move, board.current_player)
-        eng.search()
+        if self._callback is not None:
+            self._callback_playouts(eng, board)
+        else:
+            eng.search()
         visits, _, _, _ = eng.root_stats()
         acts = list(board.availables)
         probs = softmax(1.0 / temp * np.log(np.array(visits[0][acts], dtype=np.int64) + 1e-10))
         return acts, probs
+
+    def _callback_playouts(self, eng, board):
+        """n_playout times MCTS._playout (mcts_alphaZero.py:113-148) with the policy evaluated here."""
+        from .board import Board
+        S = board.width * board.height
+        for _ in range(self._n_playout):
+            s1, s2, _, last, cur, term = eng.playout_begin(0)
+            if term:
+                eng.playout_end(None, 0.0)
+                continue
+            leaf = Board.from_stones(board.width, board.height, board.n_in_row, s1, s2, last, cur)
+            action_probs, value = self._callback(leaf)
+            priors = np.zeros(S, dtype=np.float32)
+            for a, p in action_probs:
+                priors[a] = p
+            eng.playout_end(priors, float(np.float32(value)))
 
     def get_action(self, board, temp=1e-3, return_prob=0):
         """mcts_alphaZero.py:212-262"""

@@ -63,6 +63,26 @@ class Net(nn.Module):
         return a, v
 
 
+def train_step_tensors(module, optimizer, s, p, z, lr, reduce_fn=None):
+    """policy_value_net_pytorch.py:117-148 on torch tensors of any device: loss = MSE(v, z) -
+    mean(sum(pi * log p)), one optimiser step at learning rate lr; reduce_fn(module), if given, runs
+    between backward and the step (gradient averaging over ranks).  Returns (loss, entropy) as
+    0-dim tensors."""
+    optimizer.zero_grad()
+    for group in optimizer.param_groups:
+        group['lr'] = lr
+    logp, v = module(s)
+    value_loss = F.mse_loss(v.view(-1), z)
+    policy_loss = -torch.mean(torch.sum(p * logp, 1))
+    loss = value_loss + policy_loss
+    loss.backward()
+    if reduce_fn is not None:
+        reduce_fn(module)
+    optimizer.step()
+    entropy = -torch.mean(torch.sum(torch.exp(logp) * logp, 1))
+    return loss.detach(), entropy.detach()
+
+
 class PolicyValueNet(object):
     def __init__(self, board_width, board_height, model_file=None, use_gpu=True, device=0):
         if board_width != board_height:
@@ -142,7 +162,11 @@ class PolicyValueNet(object):
 
     # ---- reference surface -----------------------------------------------------
     def policy_value(self, state_batch):
-        """policy_value_net_pytorch.py:80-94: (probs [B,S], value [B,1]) as numpy."""
+        """policy_value_net_pytorch.py:80-94: (probs [B,S], value [B,1]) as numpy; a torch CUDA
+        tensor stays on the device and gives torch tensors."""
+        if torch.is_tensor(state_batch) and state_batch.is_cuda:
+            probs, vals = self._engine().eval_batch_device(state_batch.to(torch.float32))
+            return probs, vals.reshape(-1, 1)
         probs, vals = self._engine().eval_batch(np.asarray(state_batch, dtype=np.float32))
         return probs, vals.reshape(-1, 1)
 
@@ -158,22 +182,17 @@ class PolicyValueNet(object):
         weight decay 1e-4); returns Python floats (the reference's loss.data[0] indexing
         no longer works on current PyTorch)."""
         dev = self.device
-        s = torch.as_tensor(np.asarray(state_batch), dtype=torch.float32, device=dev)
-        p = torch.as_tensor(np.asarray(mcts_probs), dtype=torch.float32, device=dev)
-        z = torch.as_tensor(np.asarray(winner_batch), dtype=torch.float32, device=dev)
-        self.optimizer.zero_grad()
-        for group in self.optimizer.param_groups:
-            group['lr'] = lr
-        logp, v = self.policy_value_net(s)
-        value_loss = F.mse_loss(v.view(-1), z)
-        policy_loss = -torch.mean(torch.sum(p * logp, 1))
-        loss = value_loss + policy_loss
-        loss.backward()
+
+        def tensor(a):
+            if torch.is_tensor(a):
+                return a.to(device=dev, dtype=torch.float32)
+            return torch.as_tensor(np.asarray(a), dtype=torch.float32, device=dev)
+        reduce_fn = None
         if self.data_parallel and torch.distributed.is_available() and torch.distributed.is_initialized():
             from .dist import allreduce_gradients
-            allreduce_gradients(self.policy_value_net)       # every rank holds an equal share of the batch
-        self.optimizer.step()
-        entropy = -torch.mean(torch.sum(torch.exp(logp) * logp, 1))
+            reduce_fn = allreduce_gradients                  # every rank holds an equal share of the batch
+        loss, entropy = train_step_tensors(self.policy_value_net, self.optimizer, tensor(state_batch), tensor(mcts_probs),
+                                           tensor(winner_batch), lr, reduce_fn)
         self.version += 1
         return float(loss.item()), float(entropy.item())
 

@@ -15,16 +15,35 @@ import random
 import numpy as np
 
 from .board import Board
-from .engine import SelfPlayEngine
+from .engine import SelfPlayEngine, SelfPlayRunner
 from .game import Game
-from .train_data import ReplayBuffer, equi_data_arrays
+from .train_data import DeviceReplayBuffer
 
 
 class TrainPipeline:
+    """Keyword arguments beyond the reference's hyper-parameters:
+    n_parallel        game slots of the engine (per rank)
+    updates_per_batch policy_update calls after every collect_selfplay_data(play_batch_size).  The
+                      reference's loop (train.py:306-320) makes ONE call per collected batch and its
+                      configuration collects one game per batch (play_batch_size: 1), i.e. one update
+                      per game; here a batch is play_batch_size games played side by side, so
+                      updates_per_batch = play_batch_size reproduces that ratio and 1 (the default)
+                      reproduces the reference's code path for the given play_batch_size.
+    continuous        False: every batch is a cohort of play_batch_size fresh games played to the end
+                      with the weights of that moment (what the reference does, one game at a time).
+                      True: the slots never idle -- a finished game is replaced at once, a batch is the
+                      next play_batch_size games to finish, games in flight go on across policy updates
+                      (they see new weights from their next move on), and the policy updates of batch k
+                      are issued between the move steps of batch k+1.
+    rng               source of the mini-batch draw (random.sample): a private random.Random by
+                      default; pass the `random` module for the reference's global stream."""
+
     def __init__(self, board_width=8, board_height=8, n_in_row=5, init_model=None, learn_rate=2e-3,
                  lr_multiplier=1.0, temp=1.0, n_playout=400, c_puct=5, buffer_size=10000, batch_size=512,
                  play_batch_size=1, epochs=5, kl_targ=0.02, check_freq=50, game_batch_num=1500,
-                 n_parallel=1024, device=0, seed0=0, policy_value_net=None, pure_mcts_playout_num=1000):
+                 n_parallel=1024, device=0, seed0=0, policy_value_net=None, pure_mcts_playout_num=1000,
+                 updates_per_batch=1, continuous=False, rng=None):
+        import torch
         from .net import PolicyValueNet
         self.board_width, self.board_height, self.n_in_row = board_width, board_height, n_in_row
         self.board = Board(width=board_width, height=board_height, n_in_row=n_in_row)
@@ -32,18 +51,16 @@ class TrainPipeline:
         self.learn_rate, self.lr_multiplier, self.temp = learn_rate, lr_multiplier, temp
         self.n_playout, self.c_puct = n_playout, c_puct
         self.buffer_size, self.batch_size = buffer_size, batch_size
-        self.data_buffer = ReplayBuffer(buffer_size, board_width)            # deque(maxlen) of train.py:82
+        self._rng = rng if rng is not None else random.Random(0x5EED + seed0)
+        self.data_buffer = DeviceReplayBuffer(buffer_size, board_width, torch.device("cuda", device), self._rng)
         self.play_batch_size, self.epochs, self.kl_targ = play_batch_size, epochs, kl_targ
         self.check_freq, self.game_batch_num = check_freq, game_batch_num
+        self.updates_per_batch, self.continuous = int(updates_per_batch), bool(continuous)
         self.best_win_ratio = 0.2                                            # train.py:88
         self.pure_mcts_playout_num = pure_mcts_playout_num
         self.policy_value_net = policy_value_net or PolicyValueNet(board_width, board_height, model_file=init_model,
                                                                    device=device)
         self.device, self.seed0, self.games_played = device, seed0, 0
-        self.engine = SelfPlayEngine(board_width, n_in_row, n_playout, min(n_parallel, max(1, play_batch_size)),
-                                     c_puct, device=device)
-        self._engine_version = -1
-        self.episode_len = 0
         self.rank, self.world = 0, 1
         try:
             import torch.distributed as dist
@@ -52,57 +69,136 @@ class TrainPipeline:
                 self.policy_value_net.data_parallel = self.world > 1
         except ImportError:
             pass
+        per_rank = (max(1, play_batch_size) + self.world - 1) // self.world
+        self.engine = SelfPlayEngine(board_width, n_in_row, n_playout, min(n_parallel, per_rank), c_puct, device=device)
+        self._engine_version = -1
+        self.episode_len = 0
+        self.policy_updates = 0
+        self._runner = None                      # continuous mode: the self-play run that never stops
+        self._chunks, self._games_in_chunks = [], 0
+        self._todo = []                          # continuous mode: policy updates still to issue
 
     # ---- train.py:137-159 --------------------------------------------------------------------
+    def _new_runner(self, first, total):
+        return SelfPlayRunner(self.engine, temp=self.temp, seed0=self.seed0, first_game_id=first,
+                              game_id_stride=self.world, total=total, on_samples=self._on_samples,
+                              device_samples=True, pipelined=True, packed_samples=self.world > 1)
+
+    def _on_samples(self, chunk):
+        self._chunks.append(chunk)
+
+    def _between_steps(self):
+        """Continuous mode: one pending policy update per move step, issued while the next search
+        (already enqueued by the step) runs; after the last one the engine gets the new weights."""
+        if self._todo:
+            self._todo.pop()()
+            if not self._todo:
+                self._engine_version = self.policy_value_net.sync_engine(self.engine, self._engine_version)
+
     def collect_selfplay_data(self, n_games=1):
-        """Play n_games self-play games (ids continue from the previous call; game id g uses the
-        noise stream seeded seed0 + g), augment every tuple 8-fold and extend the replay buffer."""
-        self._engine_version = self.policy_value_net.sync_engine(self.engine, self._engine_version)
-        first = self.games_played + self.rank
-        mine = len(range(first, self.games_played + n_games, self.world))
-        res = self.engine.play_games(mine, temp=self.temp, seed0=self.seed0, first_game_id=first,
-                                     game_id_stride=self.world) if mine else dict(samples=None)
+        """Play n_games self-play games over all ranks (game id g draws its noise from the stream
+        seeded seed0 + g), augment every tuple 8-fold (get_equi_data) and extend the replay buffer.
+        Tuples stay in GPU memory from the engine to the buffer."""
+        import torch
+        mine = len(range(self.rank, n_games, self.world))        # this rank's share of the batch
+        if self.continuous:
+            if self._runner is None:
+                self._engine_version = self.policy_value_net.sync_engine(self.engine, self._engine_version)
+                self._runner = self._new_runner(self.rank, None)
+                self._runner.start()
+            run, target = self._runner, self._runner.games_delivered + mine
+            while run.games_delivered < target:
+                run.step()
+                self._between_steps()
+            while self.world > 1 and self._todo:                 # collectives below: every rank arrives with the same history
+                self._between_steps()
+        elif mine:
+            self._engine_version = self.policy_value_net.sync_engine(self.engine, self._engine_version)
+            run = self._new_runner(self.games_played + self.rank, mine)
+            run.start()
+            try:
+                while run.games_done < mine:
+                    run.step()
+            finally:
+                run.finish()
         self.games_played += n_games
-        s = res["samples"]
-        if s is None:
-            s = dict(states=np.zeros((0, 4, self.board_height, self.board_width), dtype=np.float32),
-                     pi=np.zeros((0, self.board_width * self.board_height)), z=np.zeros(0, dtype=np.float32),
-                     game_id=np.zeros(0, dtype=np.int64), ply=np.zeros(0, dtype=np.int32))
+        chunks, self._chunks = self._chunks, []
+        dev = torch.device("cuda", self.device)
+        keys = ("stones", "last", "pi", "z", "game_id", "ply") if self.world > 1 else ("states", "pi", "z", "game_id", "ply")
+        if chunks:
+            s = {k: torch.cat([c[k] for c in chunks]) for k in keys}
+        else:
+            empty = self.engine.selfplay_fetch(0, device=True, packed=self.world > 1)
+            s = {k: empty[k] for k in keys}
         if self.world > 1:
-            import torch
             from . import dist as azdist
-            dev = torch.device("cuda", self.device)
-            allt = azdist.gather_samples({k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in s.items()})
-            s = {k: v.cpu().numpy() for k, v in allt.items()}
-        order = np.lexsort((s["ply"], s["game_id"]))                          # game after game, ply after ply
+            s = azdist.gather_packed(s, self.board_width * self.board_height)
+            s["states"] = self.engine.unpack_states(s["stones"], s["last"], s["ply"])
+        order = torch.argsort(s["game_id"] * 1024 + s["ply"].to(torch.int64))   # game after game, ply after ply
         states, pi, z = s["states"][order], s["pi"][order], s["z"][order]
-        self.episode_len = int(len(z))
-        if len(z):
+        self.episode_len = int(z.shape[0])
+        if self.episode_len:
+            from .train_data import equi_data_arrays
             self.data_buffer.extend(*equi_data_arrays(self.engine, states, pi, z))
 
     # ---- train.py:161-214 --------------------------------------------------------------------
+    def _draw(self):
+        """The mini-batch positions: drawn once (rank 0) and shared, so that every rank trains on
+        slices of the SAME mini-batch whatever else has consumed random numbers on it."""
+        idx = self.data_buffer.draw(self.batch_size)
+        if self.world > 1:
+            import torch
+            import torch.distributed as dist
+            t = torch.tensor(idx, dtype=torch.int64, device=torch.device("cuda", self.device))
+            dist.broadcast(t, src=0)
+            idx = t.tolist()
+        return idx
+
     def policy_update(self):
-        state_batch, mcts_probs_batch, winner_batch = self.data_buffer.sample(self.batch_size)
+        import torch
+        state_batch, mcts_probs_batch, winner_batch = self.data_buffer.take(self._draw())
         net = self.policy_value_net
+        on_device = torch.is_tensor(state_batch)
         old_probs, old_v = net.policy_value(state_batch)
         sl = slice(self.rank, None, self.world)                               # this rank's share of the mini-batch
         kl, loss, entropy = 0.0, float("nan"), float("nan")
+        new_v = old_v
         for _ in range(self.epochs):
             loss, entropy = net.train_step(state_batch[sl], mcts_probs_batch[sl], winner_batch[sl],
                                            self.learn_rate * self.lr_multiplier)
             new_probs, new_v = net.policy_value(state_batch)
-            kl = float(np.mean(np.sum(old_probs * (np.log(old_probs + 1e-10) - np.log(new_probs + 1e-10)), axis=1)))
+            if on_device:
+                kl = float(torch.mean(torch.sum(old_probs.double() * (torch.log(old_probs.double() + 1e-10)
+                                                                      - torch.log(new_probs.double() + 1e-10)), dim=1)))
+            else:
+                kl = float(np.mean(np.sum(old_probs * (np.log(old_probs + 1e-10) - np.log(new_probs + 1e-10)), axis=1)))
+            kl = self._agree(kl)
             if kl > self.kl_targ * 4:                                         # early stopping if D_KL diverges badly
                 break
         if kl > self.kl_targ * 2 and self.lr_multiplier > 0.05:
             self.lr_multiplier /= 1.5
         elif kl < self.kl_targ / 2 and self.lr_multiplier < 10:
             self.lr_multiplier *= 1.5
-        var_z = np.var(np.array(winner_batch))
-        self.explained_var_old = 1 - np.var(np.array(winner_batch) - old_v.flatten()) / var_z if var_z > 0 else float("nan")
-        self.explained_var_new = 1 - np.var(np.array(winner_batch) - new_v.flatten()) / var_z if var_z > 0 else float("nan")
+        wz = winner_batch.double().cpu().numpy() if on_device else np.array(winner_batch)
+        ov = old_v.double().cpu().numpy().flatten() if on_device else old_v.flatten()
+        nv = new_v.double().cpu().numpy().flatten() if on_device else new_v.flatten()
+        var_z = np.var(wz)
+        self.explained_var_old = 1 - np.var(wz - ov) / var_z if var_z > 0 else float("nan")
+        self.explained_var_new = 1 - np.var(wz - nv) / var_z if var_z > 0 else float("nan")
         self.last_kl = kl
+        self.policy_updates += 1
         return loss, entropy
+
+    def _agree(self, kl):
+        """Every rank must take the same early-stop and multiplier decisions (the train steps hold
+        collectives): the largest KL any rank measured counts for all."""
+        if self.world == 1:
+            return kl
+        import torch
+        import torch.distributed as dist
+        t = torch.tensor([kl], dtype=torch.float64, device=torch.device("cuda", self.device))
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t[0])
 
     # ---- train.py:216-276 --------------------------------------------------------------------
     def policy_evaluate(self, n_games=10, batched=False, seed0=0):
@@ -140,18 +236,40 @@ class TrainPipeline:
             self.collect_selfplay_data(self.play_batch_size)
             loss = entropy = None
             if len(self.data_buffer) > self.batch_size:
-                loss, entropy = self.policy_update()
+                if self.continuous:
+                    # the updates of an earlier batch that self-play has not got round to come first
+                    while self._todo:
+                        self._between_steps()
+                    self._last = (None, None)
+
+                    def one():
+                        self._last = self.policy_update()
+                    self._todo = [one] * self.updates_per_batch
+                    if i + 1 == self.game_batch_num:
+                        while self._todo:
+                            self._between_steps()
+                    loss, entropy = self._last
+                else:
+                    for _ in range(self.updates_per_batch):
+                        loss, entropy = self.policy_update()
             if on_batch is not None:
                 on_batch(i, self.episode_len, loss, entropy)
-            if self.check_freq and (i + 1) % self.check_freq == 0 and self.rank == 0 and evaluate_games > 0:
-                win_ratio = self.policy_evaluate(evaluate_games)
-                if win_ratio > self.best_win_ratio:
-                    self.best_win_ratio = win_ratio
-                    if best_model:
-                        self.policy_value_net.save_model(best_model)
-                    if self.best_win_ratio == 1.0 and self.pure_mcts_playout_num < 5000:
-                        self.pure_mcts_playout_num += 1000
-                        self.best_win_ratio = 0.0
+            if self.check_freq and (i + 1) % self.check_freq == 0 and evaluate_games > 0:
+                if self.rank == 0:
+                    win_ratio = self.policy_evaluate(evaluate_games)
+                    if win_ratio > self.best_win_ratio:
+                        self.best_win_ratio = win_ratio
+                        if best_model:
+                            self.policy_value_net.save_model(best_model)
+                        if self.best_win_ratio == 1.0 and self.pure_mcts_playout_num < 5000:
+                            self.pure_mcts_playout_num += 1000
+                            self.best_win_ratio = 0.0
+                if self.world > 1:
+                    import torch.distributed as dist
+                    dist.barrier()                                # the other ranks wait here, not inside a later collective
+        if self._runner is not None:
+            self._runner.finish()
+            self._runner = None
         return self.policy_value_net
 
 
@@ -177,6 +295,12 @@ def main(argv=None):
     ap.add_argument("--check-freq", type=int, default=0, help="evaluate against the rollout player every this many batches (0 = never)")
     ap.add_argument("--pure-playouts", type=int, default=1000)
     ap.add_argument("--save", default=None, help="write the final state_dict here")
+    ap.add_argument("--updates-per-batch", default="1",
+                    help="policy updates after every self-play batch: a number, or 'games' for one per game of the batch "
+                         "(the ratio of the reference's configuration, play_batch_size: 1)")
+    ap.add_argument("--continuous", action="store_true",
+                    help="never idle a slot: finished games are replaced at once, policy updates run between move steps")
+    ap.add_argument("--slots", type=int, default=1024, help="game slots per GPU")
     args = ap.parse_args(argv)
     os.environ.setdefault("NCCL_DEBUG", "WARN")            # keeps most of RCCL's start-up banner off stdout
     import torch
@@ -190,12 +314,14 @@ def main(argv=None):
         rank, world = dist.get_rank(), dist.get_world_size()
     torch.manual_seed(0)                                   # every rank starts from the same weights
     random.seed(1234)                                      # and samples the same mini-batches
-    per_rank = max(1, (args.play_batch + world - 1) // world)
+    per_rank = args.slots
+    upb = args.play_batch if args.updates_per_batch == "games" else int(args.updates_per_batch)
     tp = TrainPipeline(board_width=args.board, board_height=args.board, n_in_row=args.n_in_row, learn_rate=args.lr,
                        n_playout=args.playouts, buffer_size=args.buffer_size, batch_size=args.batch_size,
                        play_batch_size=args.play_batch, epochs=args.epochs, check_freq=args.check_freq,
                        game_batch_num=(args.games + args.play_batch - 1) // args.play_batch, n_parallel=per_rank,
-                       device=local, pure_mcts_playout_num=args.pure_playouts)
+                       device=local, pure_mcts_playout_num=args.pure_playouts, updates_per_batch=upb,
+                       continuous=args.continuous)
     if world > 1:
         from . import dist as azdist
         azdist.broadcast_weights(tp.policy_value_net)
@@ -209,7 +335,9 @@ def main(argv=None):
             tp.policy_value_net.save_model(args.save)
         losses = [l for _, _, l, _ in log if l is not None]
         print(json.dumps({"games": tp.games_played, "ranks": world, "seconds": dt, "games_per_s_incl_training": tp.games_played / dt,
-                          "samples": int(sum(n for _, n, _, _ in log)), "policy_updates": len(losses),
+                          "samples": int(sum(n for _, n, _, _ in log)), "policy_updates": tp.policy_updates,
+                          "updates_per_batch": upb, "play_batch": args.play_batch, "continuous": bool(args.continuous),
+                          "slots_per_gpu": tp.engine.B,
                           "first_loss": losses[0] if losses else None, "last_loss": losses[-1] if losses else None,
                           "lr_multiplier": tp.lr_multiplier, "best_win_ratio": tp.best_win_ratio}))
     if world > 1:

@@ -33,6 +33,7 @@ extern "C" {
                                  repeated searches without a move in between (raise arena_nodes) */
 #define AZG_ESTATE       -5   /* call not valid in the current state               */
 #define AZG_EMOVE        -6   /* illegal move (occupied cell / out of range)       */
+#define AZG_ERANGE       -7   /* AZG_CNN_F16X3: an activation left the half-precision range */
 
 /* where leaf priors and values come from */
 #define AZG_PRIOR_NET        0   /* policy/value CNN (policy_value_net_pytorch.py:23-57) */
@@ -95,6 +96,19 @@ int azg_set_position(azg_handle *h, int slot, const uint64_t stones1[4],
  * Asynchronous: returns after enqueueing; later calls on the handle order after it. */
 int azg_search(azg_handle *h);
 
+/* One playout of MCTS._playout (mcts_alphaZero.py:113-148) for slot `slot`, split at the call of
+ * the policy function (:132) so that ANY policy_value_fn of the caller can supply priors and value
+ * (mcts_alphaZero.py:98-103; human_play.py passes the numpy net's method).  azg_playout_begin
+ * descends to a leaf and returns its position: stones of player 1 / 2 (bit m of word m/64), the
+ * number of stones, the last move, the side to move and terminal = 0 (game goes on), 1 / 2
+ * (winner) or -1 (tie).  azg_playout_end expands the leaf with priors[S] (float32 by cell, host or
+ * device; entries of occupied cells are ignored; not renormalised, like policy_value_net_pytorch.py:113)
+ * and backs `value` (for the side to move) up; for a terminal leaf both are ignored (priors may be
+ * NULL) and the reference's +-1 / 0 is backed up.  n_playout pairs of calls equal one azg_search. */
+int azg_playout_begin(azg_handle *h, int slot, uint64_t stones1[4], uint64_t stones2[4], int *ply,
+                      int *last_move, int *current_player, int *terminal);
+int azg_playout_end(azg_handle *h, int slot, const float *priors, double value);
+
 /* Root statistics after azg_search (mcts_alphaZero.py:166-168): per slot and per
  * cell the child's visit count (0 for occupied cells), optionally Q and P, and the
  * root's own visit count.  Outputs host or device; any may be NULL. */
@@ -151,16 +165,28 @@ int azg_drain_samples(azg_handle *h, int max_samples, float *states, double *pi,
  * enqueues the next search before it waits for anything; it reports how many games
  * ended in this step and how many samples of EARLIER finished games are now ready.
  * azg_selfplay_fetch copies those samples (layout as azg_drain_samples; host or device
- * pointers, any may be NULL) and must be called before the next step, or the samples
- * are dropped.  azg_selfplay_end waits for the work in flight, makes the samples of the
- * last finished games ready for a final fetch and returns the handle to the
- * synchronous calls (which fail with AZG_ESTATE in between). */
+ * pointers, any may be NULL) and must be called before the next step: a step taken while
+ * ready samples are unfetched fails with AZG_ESTATE (a fetch with null pointers discards
+ * them).  azg_selfplay_end waits for the work in flight, makes the samples of the last finished
+ * games ready for a final fetch and returns the handle to the synchronous calls (which fail
+ * with AZG_ESTATE in between). */
 int azg_selfplay_begin(azg_handle *h, double temp, uint32_t seed0, int64_t first_id,
                        int64_t stride, int64_t total);
 int azg_selfplay_step(azg_handle *h, int *games_finished, int *samples_ready);
 int azg_selfplay_fetch(azg_handle *h, float *states, double *pi, float *z,
                        int64_t *game_id, int32_t *ply);
 int azg_selfplay_end(azg_handle *h, int *samples_ready);
+
+/* The ready samples in packed form, for the exchange between GPUs: instead of the four feature
+ * planes (4*S floats) the position they are computed from, stones u64 [n,2,4] (bit m of word m/64
+ * of colour c) and last_move i32 [n]; pi, z, game_id, ply as azg_selfplay_fetch.  Either fetch may
+ * be called (or both) before the next step.  azg_unpack_states turns packed positions of self-play
+ * games (stone 1 opens) back into Board.current_state planes (game.py:92-116), f32 [n,4,N,N]; all
+ * pointers host or device. */
+int azg_selfplay_fetch_packed(azg_handle *h, uint64_t *stones, int32_t *last_move, double *pi,
+                              float *z, int64_t *game_id, int32_t *ply);
+int azg_unpack_states(azg_handle *h, int n, const uint64_t *stones, const int32_t *last_move,
+                      const int32_t *ply, float *states);
 
 /* The evaluation opponent of train.py:249,264: mcts_pure.MCTSPlayer.get_action
  * (mcts_pure.py:261-268) for every live slot, i.e. MCTS.get_move (mcts_pure.py:214-231) from a

@@ -1,0 +1,279 @@
+"""GPU tests of what surrounds the search: the training step and loop, the bundled trained nets,
+ties, packed samples, the host-evaluated playout, the activation-range guard, C4 at full size."""
+import numpy as np
+import pytest
+
+import helpers
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def az():
+    import alphazero_gomoku_amd as pkg
+    return pkg
+
+
+def _policy_from(ev, oracle, n, k):
+    """Oracle policy callback that returns the GPU CNN's own float32 outputs."""
+    def policy(b):
+        ob = oracle.OracleBoard(n, n, k)
+        ob.b = b
+        pr, v = ev.eval_batch(ob.current_state().astype(np.float32))
+        return [float(x) for x in pr[0]], float(v[0])
+    return policy
+
+
+def test_train_step_matches_reference(az):
+    """PolicyValueNet.train_step on the GPU against the reference's train_step (fixture g9,
+    policy_value_net_pytorch.py:117-148): loss and entropy of three steps to 1e-5, the parameters
+    after one and three Adam steps, and the HIP CNN's outputs with the updated weights against the
+    reference net's own outputs (1e-4).  Adam's first steps move every parameter by about the
+    learning rate in the direction of its gradient's sign, so a parameter whose gradient is within
+    float32 noise of zero can land 2*lr away on another device; those are counted, not hidden."""
+    d = helpers.load_golden("g9_train.npz")
+    n, k, seed = [int(x) for x in d["spec"]]
+    net = az.PolicyValueNet(n, n)
+    net.load_numpy_params(helpers.make_params(n, seed=seed))
+    v0 = net.version
+    s, p, z = d["states"].astype(np.float32), d["pi"], d["z"]
+    total = sum(int(np.prod(x.shape)) for x in helpers.make_params(n, seed=seed))
+    for step, lr in enumerate(d["lrs"]):
+        loss, ent = net.train_step(s, p, z, float(lr))
+        assert abs(loss - d["loss"][step]) < 1e-5 and abs(ent - d["entropy"][step]) < 1e-5, step
+        if step in (0, 2):
+            far, worst = 0, 0.0
+            for i, t in enumerate(net.param_tensors()):
+                diff = np.abs(t.detach().cpu().numpy() - d["params_after_%d_%d" % (step + 1, i)])
+                far += int((diff > 1e-6).sum())
+                worst = max(worst, float(np.median(diff)))
+            assert far <= total // 2000 and worst < 1e-7, (step, far, worst)
+    assert net.version == v0 + 3
+    probs, vals = net.policy_value(s[:16])
+    assert np.abs(probs - d["probs_after_3"]).max() < 1e-4 and np.abs(vals.reshape(-1) - d["values_after_3"]).max() < 1e-4
+
+
+@pytest.mark.parametrize("cnn_mode", [0, 1], ids=["f16x3", "f32"])
+def test_bundled_trained_nets_through_the_engine(az, cnn_mode):
+    """The reference's trained 6x6 and 8x8 nets (sharply peaked policies, values up to +-1): both CNN
+    variants within 1e-4 of the reference numpy net on random and played positions, and the
+    reference's seeded self-play game with each net reproduced move for move, visit for visit."""
+    d = helpers.load_golden("g10_trained.npz")
+    for g in d["games"]:
+        n, k = g["n"], g["k"]
+        params = [d["params_%d_%d" % (n, i)] for i in range(16)]
+        eng = az.SelfPlayEngine(n, k, g["n_playout"], 1, float(g["c_puct"]), cnn_mode=cnn_mode)
+        eng.set_weights(params, layout=az._lib.LAYOUT_THEANO)
+        probs, vals = eng.eval_batch(d["states_%d" % n].astype(np.float32))
+        dp, dv = np.abs(probs - d["probs_%d" % n]).max(), np.abs(vals - d["values_%d" % n]).max()
+        assert dp < 1e-4 and dv < 1e-4, (g["model"], dp, dv)
+        assert dp < 2e-6 and dv < 2e-6, (g["model"], dp, dv)          # what both variants actually reach
+        eng.reset_games(seeds=np.array([g["seed"]], dtype=np.uint32))
+        for t in range(len(g["moves"])):
+            eng.search()
+            visits, _, _, _ = eng.root_stats()
+            assert np.array_equal(visits[0], g["visits"][t]), (g["model"], t)
+            moves, pi = eng.sample_and_advance(float(g["temp"]))
+            assert moves[0] == g["moves"][t], (g["model"], t)
+            np.testing.assert_allclose(pi[0], g["pi"][t], rtol=0, atol=1e-12)
+        ended, winner, _ = eng.status()
+        assert ended[0] and winner[0] == g["winner"]
+        assert np.array_equal(eng.drain_samples()["z"], g["z"].astype(np.float32))
+        eng.close()
+
+
+def test_activation_range_guard(az):
+    """Split-f16 operands overflow above 65504: an activation that large must raise (sticky, named),
+    never return numbers; the float32 variant evaluates the same net."""
+    n = 8
+    params = helpers.make_params(n, seed=1)
+    params[1] = np.full(32, 1.0e5, dtype=np.float32)                    # conv1 bias: activations of 1e5
+    st = np.zeros((2, 4, n, n), dtype=np.float32)
+    st[:, 3] = 1.0
+    ok = az.SelfPlayEngine(n, 5, 16, 1, cnn_mode=az._lib.CNN_F32)
+    ok.set_weights(params)
+    probs, vals = ok.eval_batch(st)
+    assert np.isfinite(probs).all() and np.isfinite(vals).all()
+    ok.close()
+    eng = az.SelfPlayEngine(n, 5, 16, 1)
+    eng.set_weights(params)
+    with pytest.raises(az._lib.AzgError, match="AZG_ERANGE"):
+        eng.eval_batch(st)
+    eng.reset_games()
+    eng.search()
+    with pytest.raises(az._lib.AzgError, match="AZG_ERANGE"):
+        eng.status()
+    eng.close()
+
+
+def test_tie_games_through_pipelined_selfplay(az):
+    """Seeded 3x3 games recorded from the reference, ties among them (game.py:396-399: z = 0 for
+    every ply), played through azg_selfplay_* with finished slots restarted on the device."""
+    games = helpers.load_golden("g11_ties.npz")["games"]
+    seed0 = min(g["seed"] for g in games)
+    by_seed = {g["seed"]: g for g in games}
+    assert sorted(by_seed) == list(range(seed0, seed0 + len(games)))
+    eng = az.SelfPlayEngine(3, 3, games[0]["n_playout"], 7, 5.0, prior_mode=az.PRIOR_HASH)
+    res = eng.play_games(len(games), temp=1.0, seed0=seed0, pipelined=True)
+    s = res["samples"]
+    ties = 0
+    for gid in range(len(games)):
+        g = by_seed[seed0 + gid]
+        sel = np.nonzero(s["game_id"] == gid)[0]
+        sel = sel[np.argsort(s["ply"][sel])]
+        assert len(sel) == len(g["moves"]), gid
+        assert np.array_equal(s["z"][sel], g["z"].astype(np.float32)), gid
+        assert np.array_equal(s["states"][sel], g["states"].astype(np.float32)), gid
+        np.testing.assert_allclose(s["pi"][sel], g["pi"], rtol=0, atol=1e-12)
+        if g["winner"] == -1:
+            ties += 1
+            assert len(sel) == 9 and not s["z"][sel].any()
+    assert ties >= 2
+    eng.close()
+
+
+def test_packed_samples_and_unfetched_samples(az):
+    """azg_selfplay_fetch_packed + azg_unpack_states give the planes azg_selfplay_fetch gives, and a
+    move step taken while ready samples are unfetched is refused instead of dropping them."""
+    import torch
+    from alphazero_gomoku_amd.engine import SelfPlayRunner
+    n, k = 8, 5
+    outs = []
+    for packed in (False, True):
+        eng = az.SelfPlayEngine(n, k, 32, 24, prior_mode=az.PRIOR_HASH)
+        got = []
+        run = SelfPlayRunner(eng, 1.0, 77, 0, 1, 60, got.append, device_samples=True, pipelined=True, packed_samples=packed)
+        run.start()
+        while run.games_done < 60:
+            run.step()
+        run.finish()
+        t = {key: torch.cat([c[key] for c in got]) for key in got[0]}
+        if packed:
+            t["states"] = eng.unpack_states(t["stones"], t["last"], t["ply"])
+        outs.append({key: v.cpu().numpy() for key, v in t.items()})
+        eng.close()
+    a, b = outs
+    assert len(a["z"]) == len(b["z"]) > 500
+    for key in ("states", "pi", "z", "game_id", "ply"):
+        assert np.array_equal(a[key], b[key]), key
+    eng = az.SelfPlayEngine(n, k, 32, 24, prior_mode=az.PRIOR_HASH)
+    eng.selfplay_begin(seed0=77)
+    with pytest.raises(az._lib.AzgError, match="not fetched"):
+        for _ in range(64):
+            eng.selfplay_step()                                  # some game ends, its samples become ready ...
+    ready = eng.selfplay_end()
+    eng.selfplay_fetch(ready)
+    eng.close()
+
+
+def test_callback_player_reproduces_reference_game(az, oracle):
+    """MCTSPlayer with an arbitrary policy_value_fn (mcts_alphaZero.py:98-103): configuration C1's
+    game of the reference (6x6, 4 in a row, 200 playouts, numpy net) with a host-side net as the
+    callback -- the GPU selects, the host evaluates, the GPU expands and backs up."""
+    g = [x for x in helpers.load_golden("g3_games.npz")["games"] if x["cb"] == "numpy_net_f32"][0]
+    n, k = g["n"], g["k"]
+    net = oracle.OracleNet(n, n, helpers.make_params(n, seed=106), precise=True)
+    calls = [0]
+
+    def policy_value_fn(board):
+        calls[0] += 1
+        p, v = net.forward(board.current_state())
+        return zip(board.availables, [float(np.float32(p[a])) for a in board.availables]), float(np.float32(v))
+    player = az.MCTSPlayer(policy_value_fn, c_puct=g["c_puct"], n_playout=g["n_playout"], is_selfplay=1)
+    np.random.seed(g["seed"])
+    winner, data = az.Game(az.Board(width=n, height=n, n_in_row=k)).start_self_play(player, temp=g["temp"])
+    data = list(data)
+    assert winner == g["winner"] and len(data) == len(g["moves"])
+    for t, (st, pi, z) in enumerate(data):
+        assert np.array_equal(st, g["states"][t]) and z == g["z"][t], t
+        np.testing.assert_allclose(pi, g["pi"][t], rtol=0, atol=1e-12)
+    assert calls[0] > 0.9 * g["n_playout"] * len(g["moves"]) - 400
+
+
+def test_c4_full_size_slots_against_oracle(az, oracle):
+    """Configuration C4 at full size (512 games of 15x15, 5 in a row, 800 playouts, CNN): slots 0,
+    255 and 511 over three plies against the oracle's tree fed the GPU CNN's own outputs -- every
+    root visit count and Q bit-equal, tree reuse included."""
+    n, k, npo, B = 15, 5, 800, 512
+    params = helpers.make_params(n, seed=115)
+    eng = az.SelfPlayEngine(n, k, npo, B, 5.0)
+    eng.set_weights(params)
+    ev = az.SelfPlayEngine(n, k, 1, 1)
+    ev.set_weights(params)
+    eng.reset_games(seeds=np.arange(B, dtype=np.uint32) + 9000)
+    slots = (0, 255, 511)
+    trees = {g: oracle.OracleMCTS(_policy_from(ev, oracle, n, k), c_puct=5, n_playout=npo) for g in slots}
+    boards = {}
+    for g in slots:
+        boards[g] = oracle.OracleBoard(n, n, k)
+        boards[g].init_board()
+    for ply in range(3):
+        eng.search()
+        visits, q, p, rn = eng.root_stats()
+        moves, _ = eng.sample_and_advance(1.0, want_pi=False)
+        for g in slots:
+            acts, ovis, oq, op, _ = trees[g].get_move_probs(boards[g], temp=1.0)
+            assert rn[g] == trees[g].root_visits(), (g, ply)
+            assert np.array_equal(visits[g][acts], ovis) and np.array_equal(q[g][acts], oq) and np.array_equal(p[g][acts], op), (g, ply)
+            trees[g].update_with_move(int(moves[g]))
+            boards[g].do_move(int(moves[g]))
+    eng.close()
+    ev.close()
+
+
+def test_training_loop_c5_shape(az):
+    """The loop of configuration C5 in small: 8x8, two batches of 256 games with policy updates.
+    The replay buffer holds 8 tuples per ply in get_equi_data's order (train.py:116-135), the
+    engine plays the second batch with updated weights, every update trains on the whole mini-batch."""
+    import torch
+    from alphazero_gomoku_amd.train import TrainPipeline
+    from alphazero_gomoku_amd.train_data import equi_data_arrays
+    torch.manual_seed(0)
+    tp = TrainPipeline(board_width=8, board_height=8, n_in_row=5, n_playout=48, play_batch_size=256, n_parallel=256,
+                       buffer_size=400000, batch_size=512, epochs=3, game_batch_num=2, check_freq=0, updates_per_batch=4)
+    log = []
+    v0 = tp.policy_value_net.version
+    tp.run(on_batch=lambda i, n_samples, loss, ent: log.append((i, n_samples, loss, ent, tp._engine_version)))
+    assert tp.games_played == 512 and tp.policy_updates == 8
+    assert len(tp.data_buffer) == 8 * (log[0][1] + log[1][1])
+    assert all(np.isfinite(l[2]) and np.isfinite(l[3]) for l in log)
+    assert log[1][4] > log[0][4] >= v0 + 1                  # the engine's weights moved on between the batches
+    assert tp.policy_value_net.version >= v0 + 8
+    # buffer rows 0..7 are the eight images of one tuple; image 6 is the rotation by 4 * 90 degrees,
+    # i.e. the tuple itself (train.py:121-128)
+    buf = tp.data_buffer
+    assert buf.start == 0
+    so, po, zo = equi_data_arrays(tp.engine, buf.states[6:7].float(), buf.pi[6:7], buf.z[6:7])
+    assert torch.equal(so, buf.states[0:8].float()) and torch.equal(po, buf.pi[0:8]) and torch.equal(zo, buf.z[0:8])
+    # continuous mode: slots never idle, updates run between move steps
+    tp2 = TrainPipeline(board_width=8, board_height=8, n_in_row=5, n_playout=48, play_batch_size=128, n_parallel=128,
+                        buffer_size=400000, batch_size=512, epochs=2, game_batch_num=3, check_freq=0, updates_per_batch=2,
+                        continuous=True)
+    tp2.run()
+    assert tp2.games_played == 384 and tp2.policy_updates == 6 and len(tp2.data_buffer) > 8 * 384 * 8
+
+
+def test_device_replay_buffer_matches_deque(az):
+    """DeviceReplayBuffer against collections.deque(maxlen) + random.sample (train.py:82,155,167)."""
+    import collections
+    import random
+    import torch
+    from alphazero_gomoku_amd.train_data import DeviceReplayBuffer
+    n = 6
+    dev = torch.device("cuda", 0)
+    rng = np.random.RandomState(3)
+    buf, ref = DeviceReplayBuffer(50, n, dev, rng=random), collections.deque(maxlen=50)
+    for kk in (3, 19, 7, 30, 64, 1, 49, 50, 12):
+        st = (rng.rand(kk, 4, n, n) < 0.4).astype(np.float32)
+        pi = rng.rand(kk, n * n)
+        z = rng.choice([-1.0, 0.0, 1.0], size=kk).astype(np.float32)
+        buf.extend(torch.from_numpy(st).to(dev), torch.from_numpy(pi).to(dev), torch.from_numpy(z).to(dev))
+        ref.extend([(st[i], pi[i], z[i]) for i in range(kk)])
+        assert len(buf) == len(ref)
+        m = min(8, len(ref))
+        random.seed(11)
+        want = random.sample(ref, m)
+        random.seed(11)
+        s2, p2, z2 = [x.cpu().numpy() for x in buf.sample(m)]
+        for i in range(m):
+            assert np.array_equal(s2[i], want[i][0]) and np.array_equal(p2[i], want[i][1].astype(np.float32)) and z2[i] == want[i][2]

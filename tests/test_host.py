@@ -32,8 +32,14 @@ def test_no_cpu_fallback():
         az.SelfPlayEngine(8, 5, 10, 1)
     with pytest.raises(RuntimeError):
         az.PolicyValueNet(8, 8)
+    # an arbitrary callback is accepted (evaluated per playout), but the search itself still needs the GPU
+    player = az.MCTSPlayer(lambda board: ([], 0.0), n_playout=2)
+    board = az.Board(width=6, height=6, n_in_row=4)
+    board.init_board()
+    with pytest.raises(az._lib.AzgError):
+        player.get_action(board)
     with pytest.raises(TypeError):
-        az.MCTSPlayer(lambda board: ([], 0.0))
+        az.MCTSPlayer(3.14)
 
 
 def test_host_board_matches_reference_rules():
@@ -217,3 +223,109 @@ def test_data_parallel_train_step_two_ranks_gloo():
     for a, b, w in zip(res[0][1], res[1][1], want):
         assert np.array_equal(a, b)
         np.testing.assert_allclose(a, w.numpy(), rtol=0, atol=2e-6)
+
+
+def test_policy_update_schedule_matches_reference():
+    """TrainPipeline.policy_update against the reference's own method (train.py:161-214, run by
+    tools/gen_golden_r2.py on scripted nets): for every scripted sequence of KL values the same
+    number of train steps at the same learning rates, the same lr_multiplier afterwards, the same
+    return value."""
+    import collections
+    import random
+    from alphazero_gomoku_amd.train import TrainPipeline
+    from alphazero_gomoku_amd.train_data import ReplayBuffer
+    scen = helpers.load_golden("g9_train.npz")["policy_update"]
+    assert len(scen) >= 6
+
+    class Scripted:
+        def __init__(self, tables):
+            self.tables, self.calls, self.lrs = tables, 0, []
+
+        def policy_value(self, state_batch):
+            t = self.tables[min(self.calls, len(self.tables) - 1)]
+            self.calls += 1
+            return t, np.linspace(-0.5, 0.5, len(state_batch)).reshape(-1, 1)
+
+        def train_step(self, s, p, w, lr):
+            self.lrs.append(lr)
+            return 1.0 + len(self.lrs), 2.0
+    for sc in scen:
+        nb, S = sc["tables"].shape[1], sc["tables"].shape[2]
+        tp = TrainPipeline.__new__(TrainPipeline)
+        tp.batch_size, tp.epochs, tp.learn_rate, tp.kl_targ = nb, 5, 2e-3, 0.02
+        tp.lr_multiplier = sc["lr_multiplier_before"]
+        tp.rank, tp.world, tp.policy_updates = 0, 1, 0
+        tp.data_buffer = ReplayBuffer(100, 3, rng=random.Random(3))
+        tp.data_buffer.extend(np.zeros((nb, 4, 3, 3), dtype=np.float32), np.ones((nb, S)) / S,
+                              np.array([float((-1) ** i) for i in range(nb)], dtype=np.float32))
+        tp.policy_value_net = Scripted(list(sc["tables"]))
+        loss, ent = tp.policy_update()
+        assert len(tp.policy_value_net.lrs) == sc["train_steps"], sc["name"]
+        np.testing.assert_allclose(tp.policy_value_net.lrs, sc["lrs"], rtol=1e-15)
+        assert tp.lr_multiplier == sc["lr_multiplier_after"], sc["name"]
+        assert (loss, ent) == (sc["loss"], sc["entropy"]), sc["name"]
+        assert abs(tp.last_kl - sc["kls"][sc["train_steps"] - 1]) < 1e-15
+
+
+def test_train_step_matches_reference_on_cpu():
+    """train_step_tensors (the arithmetic of PolicyValueNet.train_step) on the CPU against the
+    reference's PolicyValueNet.train_step (policy_value_net_pytorch.py:117-148, run by
+    tools/gen_golden_r2.py): parameters after one and after three Adam steps at changing learning
+    rates, loss and entropy of every step."""
+    import torch
+    from alphazero_gomoku_amd.net import Net, PARAM_ORDER, train_step_tensors
+    d = helpers.load_golden("g9_train.npz")
+    n, k, seed = [int(x) for x in d["spec"]]
+    net = Net(n, n)
+    sd = net.state_dict()
+    for key, p in zip(PARAM_ORDER, helpers.make_params(n, seed=seed)):
+        sd[key].copy_(torch.from_numpy(p.copy()))
+    opt = torch.optim.Adam(net.parameters(), weight_decay=1e-4)
+    s, p, z = (torch.from_numpy(d[key].astype(np.float32)) for key in ("states", "pi", "z"))
+    for step, lr in enumerate(d["lrs"]):
+        loss, ent = train_step_tensors(net, opt, s, p, z, float(lr))
+        assert abs(float(loss) - d["loss"][step]) < 1e-6 and abs(float(ent) - d["entropy"][step]) < 1e-6
+        if step in (0, 2):
+            for i, key in enumerate(PARAM_ORDER):
+                np.testing.assert_allclose(net.state_dict()[key].numpy(), d["params_after_%d_%d" % (step + 1, i)],
+                                           rtol=0, atol=1e-7, err_msg="%s after step %d" % (key, step + 1))
+
+
+def _packed_worker(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+    from alphazero_gomoku_amd import dist as azdist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n, S = 2 + 3 * rank, 36                                # ragged: 2 and 5 tuples
+    g = torch.Generator().manual_seed(rank)
+    t = {"stones": torch.randint(-2 ** 62, 2 ** 62, (n, 2, 4), generator=g, dtype=torch.int64),
+         "last": torch.arange(n, dtype=torch.int32) - 1, "ply": torch.arange(n, dtype=torch.int32) + 10 * rank,
+         "z": torch.tensor([(-1.0) ** i for i in range(n)]), "game_id": torch.arange(n, dtype=torch.int64) * world + rank,
+         "pi": torch.rand((n, S), generator=g, dtype=torch.float64)}
+    rows = azdist.pack_samples(t)
+    back = azdist.unpack_samples(rows, S)
+    ok = all(torch.equal(back[key], t[key]) for key in t) and tuple(rows.shape) == (n, 84 + 8 * S)
+    out = azdist.gather_packed(t, S)
+    q.put((rank, ok, {key: v.numpy() for key, v in out.items()}, {key: v.numpy() for key, v in t.items()}))
+    dist.destroy_process_group()
+
+
+def test_packed_gather_two_ranks_gloo():
+    """Training tuples travel as one byte matrix per rank (stones, last move, ply, z, game id, pi):
+    pack / unpack is lossless, and both ranks end up with both ranks' tuples, rank after rank."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_packed_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=180) for _ in range(2)), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+    assert res[0][1] and res[1][1]
+    for key in res[0][3]:
+        want = np.concatenate([res[0][3][key], res[1][3][key]])
+        assert np.array_equal(res[0][2][key], want) and np.array_equal(res[1][2][key], want), key

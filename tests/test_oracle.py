@@ -139,22 +139,58 @@ def test_cnn_against_reference_outputs(oracle):
                 np.testing.assert_allclose(p, d["probs_torch_" + tag][i], rtol=0, atol=1e-5)
 
 
+def _assert_same_game(r, g, tag):
+    assert np.array_equal(r["moves"], g["moves"]) and r["winner"] == g["winner"], tag
+    assert np.array_equal(r["visits"], g["visits"]), tag
+    assert np.array_equal(r["z"], g["z"]), tag
+    np.testing.assert_allclose(r["pi"], g["pi"], rtol=0, atol=1e-12)
+    assert np.array_equal(r["states"], g["states"].astype(np.float64)), tag
+
+
 def test_config1_game_with_net(oracle):
-    """6x6, 4 in a row, 200 playouts, net-driven game: the oracle's net is not bitwise the
-    numpy net (different summation order), so only the opening plies are required to match."""
+    """Configuration C1 (6x6, 4 in a row, 200 playouts, numpy net) as the reference played it:
+    the oracle's net sums in another order than the numpy net, but both round their outputs to
+    float32 before the tree sees them, and the whole game comes out the same: every move, every
+    visit count, pi, z, the winner."""
     games = load("g3_games.npz")["games"]
     g = [x for x in games if x["cb"] == "numpy_net_f32"][0]
     net = oracle.OracleNet(6, 6, helpers.make_params(6, seed=106), precise=True)
     r = oracle.self_play(6, 4, "net", 5, 200, 1.0, 0, net=net)
-    assert np.array_equal(r["visits"][0], g["visits"][0])
-    same = sum(int(a == b) for a, b in zip(r["moves"], g["moves"]))
-    assert same >= 1
+    _assert_same_game(r, g, "C1")
+
+
+def test_bundled_trained_nets(oracle):
+    """The reference's trained 6x6 and 8x8 nets (mode/best_policy_6_6_4.model, best_policy_8_8_5.model,
+    read without unpickling by tools/gen_golden_r2.py): the oracle's forward pass against the
+    reference numpy net's outputs on random and played positions, and the reference's seeded
+    self-play game with each net (C1's exact setting for 6x6) move for move."""
+    d = load("g10_trained.npz")
+    for g in d["games"]:
+        n, k = g["n"], g["k"]
+        params = helpers.torch_to_theano_layout([d["params_%d_%d" % (n, i)] for i in range(16)])   # the mapping is its own inverse
+        net = oracle.OracleNet(n, n, params, precise=True)
+        for st, pr, v in zip(d["states_%d" % n], d["probs_%d" % n], d["values_%d" % n]):
+            p, val = net.forward(st.astype(np.float64))
+            np.testing.assert_allclose(p, pr, rtol=0, atol=1e-9)
+            assert abs(val - v) < 1e-8
+        r = oracle.self_play(n, k, "net", g["c_puct"], g["n_playout"], g["temp"], g["seed"], net=net)
+        _assert_same_game(r, g, g["model"])
+
+
+def test_tie_games(oracle):
+    """Seeded 3x3 games of the reference, a fifth of them ties (game.py:396-399: every z is 0,
+    winner -1)."""
+    games = load("g11_ties.npz")["games"]
+    assert sum(g["winner"] == -1 for g in games) >= 2
+    for g in games:
+        r = oracle.self_play(3, 3, "hash", 5, g["n_playout"], 1.0, g["seed"])
+        _assert_same_game(r, g, g["seed"])
 
 
 def test_equi_data_restatement_matches_fixture(oracle):
-    """get_equi_data (train.py:116-135): the oracle's numpy restatement against the fixture built
-    from explicit index loops (train.py itself is not importable here: parity unpinned by a
-    reference run)."""
+    """get_equi_data (train.py:116-135): the oracle's numpy restatement against the outputs of the
+    reference's own function body (tools/gen_golden_r2.py compiles that one method out of
+    train.py's syntax tree; the module as a whole cannot be imported)."""
     d = np.load(os.path.join(os.path.dirname(__file__), "golden", "g6_equi.npz"))
     for n in (6, 8, 15):
         states, pi, z = d["states_%d" % n], d["pi_%d" % n], d["z_%d" % n]
@@ -167,13 +203,12 @@ def test_equi_data_restatement_matches_fixture(oracle):
 
 def test_config2_game_with_net(oracle):
     """8x8, 5 in a row, 400 playouts (the benchmark's per-game settings), net-driven game recorded
-    from the reference: the oracle's first search from the empty board must give the reference's
-    visit counts; later plies may part ways (summation order of the two CPU nets differs)."""
+    from the reference: the oracle must play the reference's
+    game: every move, every visit count, pi, z and the winner."""
     g = [x for x in load("g7_net8.npz")["games"] if int(x["n"]) == 8][0]
     net = oracle.OracleNet(8, 8, helpers.make_params(8, seed=int(g["param_seed"])), precise=True)
     r = oracle.self_play(8, 5, "net", 5, 400, 1.0, int(g["seed"]), net=net)
-    assert np.array_equal(r["visits"][0], g["visits"][0])
-    assert r["moves"][0] == g["moves"][0]
+    _assert_same_game(r, g, "C2 game")
 
 
 def _oracle_board(oracle, n, k, start_player, pre=()):
