@@ -26,6 +26,13 @@ namespace azg {
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 
+// ReLU that lets a NaN through (max(x, 0) would replace it by 0).  An activation beyond the
+// half-precision range gets an infinite high half and a low half of the opposite infinity; the next
+// layer then forms inf - inf = NaN, and because every ReLU on the way passes it on, the NaN reaches
+// all outputs of that position, where the kernels test for it (error AZG_ERANGE) instead of
+// returning numbers computed from clipped activations.
+__device__ inline float relu_nan(float v) { return v < 0.0f ? 0.0f : v; }
+
 constexpr float kWScale = 256.0f;            // weights are stored as half(w * 2^8)
 constexpr float kWUnscale = 1.0f / 256.0f;
 
@@ -431,7 +438,7 @@ __device__ inline void cnn16_tail_sparse(const NetWeights &nw, float *lds, int t
                 const float *pp = lds + G::HP_OFF + c * G::NTP + cell;
                 v = __builtin_fmaf((pp[0] + pp[8 * G::NTP]) + (pp[16 * G::NTP] + pp[24 * G::NTP]), kWUnscale, bh[c]);
             }
-            const bool nz = v > 0.0f;
+            const bool nz = !(v <= 0.0f);                    // a NaN counts as non-zero (see relu_nan)
             const unsigned long long m = __ballot(nz);
             if (nz) {
                 const int at = n + __popcll(m & ((1ULL << lane) - 1ULL));
@@ -517,7 +524,7 @@ __device__ inline void cnn16_tail_sparse(const NetWeights &nw, float *lds, int t
         float hdn = lb[G::B_VFC1 + lane];
 #pragma unroll
         for (int w = 0; w < 16; w++) hdn += lds[G::SPV_OFF + w * 64 + lane];
-        hdn = hdn > 0.0f ? hdn : 0.0f;
+        hdn = relu_nan(hdn);
         mx = wave_max_f32(mx);
         float sum = 0.0f;
 #pragma unroll
@@ -578,7 +585,7 @@ __device__ inline void cnn16_tail(const NetWeights &nw, float *lds, int tid, Pro
 #pragma unroll
                     for (int i = 0; i < 4; i++) {
                         const float v = __builtin_fmaf((p0[i] + p1[i]) + (p2[i] + p3[i]), kWUnscale, b);
-                        s[i] = v > 0.0f ? v : 0.0f;
+                        s[i] = relu_nan(v);
                     }
                 }
                 half4 h, l;
@@ -600,7 +607,7 @@ __device__ inline void cnn16_tail(const NetWeights &nw, float *lds, int tid, Pro
                 const int c = pol ? cc : 4 + cc, p = leaf * G::S + cell;
                 const float *pp = lds + G::HP_OFF + c * G::NTP + p;
                 s = __builtin_fmaf((pp[0] + pp[8 * G::NTP]) + (pp[16 * G::NTP] + pp[24 * G::NTP]), kWUnscale, bh[c]);
-                s = s > 0.0f ? s : 0.0f;
+                s = relu_nan(s);
             }
             const _Float16 hi = (_Float16)s;
             _Float16 *dst = xb + (pol ? 0 : 2 * G::T * G::KPP) + leaf * kp + k;
@@ -664,7 +671,7 @@ __device__ inline void cnn16_tail(const NetWeights &nw, float *lds, int tid, Pro
             if (a < G::S) lds[G::LG_OFF + leaf * G::S + a] = expf((x[i] - mx) - lse);
         }
         float hdn = fc_out(G::OTP * 16 + lane, lb[G::B_VFC1 + lane]);
-        hdn = hdn > 0.0f ? hdn : 0.0f;
+        hdn = relu_nan(hdn);
         float v = hdn * lb[G::B_WVFC2 + lane];
         v = wave_sum_f32(v);
         if (lane == 0) lds[G::VAL_OFF + leaf] = tanhf(v + lb[G::B_VFC2]);
@@ -740,7 +747,7 @@ __device__ inline void cnn16_forward(const NetWeights &nw_in, float *lds, InputF
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
                     float v = __builtin_fmaf(acc[4 * g + e], kWUnscale, c.b[g][e]);
-                    v = v > 0.0f ? v : 0.0f;
+                    v = relu_nan(v);
                     const _Float16 hh = (_Float16)v;
                     h[e] = hh;
                     l[e] = (_Float16)(v - (float)hh);
@@ -799,7 +806,7 @@ __device__ inline void cnn16_forward(const NetWeights &nw_in, float *lds, InputF
                     for (int e = 0; e < 8; e++) {
                         const int r = 8 * s2 + e;
                         float v = __builtin_fmaf(acc[r], kWUnscale, c.b[r >> 2][r & 3]);
-                        v = v > 0.0f ? v : 0.0f;
+                        v = relu_nan(v);
                         const _Float16 hh = (_Float16)v;
                         xh8[e] = hh;
                         xl8[e] = (_Float16)(v - (float)hh);

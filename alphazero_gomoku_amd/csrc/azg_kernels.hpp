@@ -146,12 +146,15 @@ __device__ __forceinline__ void search_body(DevState st)
                 v = term == 3 ? 0.0 : (term == cur_player ? 1.0 : -1.0);
             } else if (MODE == 0) {
                 const float *probs = smem + G::LG_OFF + wave * G::S;
-                wave_expand(st, tv, gl, d, g, lane, [=](int c) { return probs[c]; });
                 const float vf = smem[G::VAL_OFF + wave];
                 // an activation beyond the half-precision range makes its high half infinite, the
-                // next layer then forms inf - inf: a NaN that reaches every output of the position
-                if (F16 && !(vf == vf) && lane == 0) st.err[g] |= 4;
-                v = (double)vf;
+                // next layer then forms inf - inf: a NaN that reaches every output of the position.
+                // The slot is flagged (the host reports AZG_ERANGE) and NOTHING of such an evaluation
+                // enters the tree: a NaN score would leave the PUCT argmax without a winner.
+                const bool bad = F16 && (!(vf == vf) || !(probs[0] == probs[0]));
+                if (bad && lane == 0) st.err[g] |= 4;
+                wave_expand(st, tv, gl, d, g, lane, [=](int c) { return bad ? 0.0f : probs[c]; });
+                v = bad ? 0.0 : (double)vf;
             } else if (MODE == 1) {
                 const float p = 1.0f / (float)(st.S - d.ply);
                 wave_expand(st, tv, gl, d, g, lane, [=](int) { return p; });

@@ -299,7 +299,9 @@ __device__ inline Descent wave_select(const DevState &st, const TreeView &t, GL 
         // first maximum in ascending child order: the wave maximum, then the lowest child index
         // among the lanes that hold it (a lane already kept its own first maximum)
         const double rs = wave_max_f64(best);
-        const int ri = wave_min_i32(best == rs ? bidx : 0x7fffffff);
+        // (a score that compares with nothing -- a NaN -- would leave no lane holding the maximum;
+        // the index is kept inside the node's block whatever the scores are)
+        const int ri = min(wave_min_i32(best == rs ? bidx : 0x7fffffff), K - 1);
         const int src = ri & 63;
         e = child + ri;
         child = __builtin_amdgcn_readlane(bchild, src);

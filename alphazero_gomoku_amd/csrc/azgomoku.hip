@@ -1007,6 +1007,7 @@ extern "C" int azg_playout_end(azg_handle *h, int slot, const float *priors, dou
     if (!h) return AZG_EINVAL;
     NOT_WHILE_PIPELINED(h);
     if (h->playout_parked != slot || slot < 0) return fail(h, AZG_ESTATE, "azg_playout_begin has not been called for slot %d", slot);
+    if (!std::isfinite(value)) return fail(h, AZG_EINVAL, "the leaf value must be finite");
     HIPCHK(h, hipSetDevice(h->cfg.device));
     const int S = h->st.S;
     void *dp;

@@ -106,6 +106,8 @@ class SelfPlayEngine:
             return
         p = np.ascontiguousarray(priors, dtype=np.float32)
         assert p.shape == (self.S,)
+        if not np.isfinite(p).all():
+            raise ValueError("policy_value_fn returned a prior that is not finite")
         self._chk(self.L.azg_playout_end(self.h, int(slot), C.c_void_p(p.ctypes.data), float(value)))
 
     def pure_search(self, n_playout, mt_state):
