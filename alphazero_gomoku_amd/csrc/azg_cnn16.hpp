@@ -33,6 +33,17 @@ typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 // returning numbers computed from clipped activations.
 __device__ inline float relu_nan(float v) { return v < 0.0f ? 0.0f : v; }
 
+#ifndef AZG_CW
+#define AZG_CW 1            // output-channel tiles per wave in conv2 / conv3 (see ConvSplit)
+#endif
+constexpr int kHeadParts = 4 / AZG_CW;      // partial sums of the head convolutions per position (one per channel group of conv3)
+// sum of a position's head partials (kHeadParts blocks of 8 rows, ntp floats per row, apart)
+__device__ inline float head_sum(const float *pp, int ntp)
+{
+    if (kHeadParts == 4) return (pp[0] + pp[8 * ntp]) + (pp[16 * ntp] + pp[24 * ntp]);
+    return pp[0] + pp[8 * ntp];
+}
+
 constexpr float kWScale = 256.0f;            // weights are stored as half(w * 2^8)
 constexpr float kWUnscale = 1.0f / 256.0f;
 
@@ -93,30 +104,50 @@ struct Cnn16Geom {
     static_assert(END_BYTES % 8 == 0, "GameLds behind the CNN region needs 8-byte alignment");
 };
 
-// The weight (A operand) stream of one wave for one layer runs RING k-steps ahead of the
-// MFMAs in a ring of register pairs.  conv_preload requests the first RING k-steps; it is
-// called well before the layer starts (during the previous layer or the input fill) so that
-// the L2 latency of the first k-steps is not exposed after the barrier that opens the layer.
-template <int RING>
-struct WRing {
-    half8 ah[RING], al[RING];
+// Work split of one 3x3 layer over the four waves: a wave owns CW output-channel tiles (of 32) and
+// PT position tiles (of 32) and keeps their CW*PT accumulators; per k-step it loads CW weight
+// operands (global memory / L2) and PT activation operands (LDS) for CW*PT products.  With CT =
+// COUT/32 channel tiles the waves form WC = CT/CW channel groups x WP = 4/WC position groups.
+// CW = 2 everywhere: against one channel tile per wave it halves the LDS reads of a k-step (every
+// activation operand then feeds two channel tiles) for twice the weight loads -- 8 KB instead of
+// 10 KB of operands per k-step of conv3, split evenly between the LDS and the vector-memory path.
+template <class G, int COUT, int CW>
+struct ConvSplit {
+    static constexpr int CT = COUT / 32, WC = CT / CW, WP = 4 / WC;
+    static constexpr int PT = (G::NT + WP - 1) / WP;
+    static_assert(CT % CW == 0 && 4 % WC == 0, "channel tiles must split evenly over the waves");
 };
 
-template <int CINP, int COUT, int RING>
-__device__ inline gptr<half8> conv_wrow(const half8 *wp, int wave, int lane)
+// The weight (A operand) stream of one wave for one layer runs RING k-steps ahead of the
+// MFMAs in a ring of register pairs per channel tile.
+template <int RING, int CW>
+struct WRing {
+    half8 ah[RING][CW], al[RING][CW];
+};
+
+// this lane's 16 halves of k-step 0 of channel tile `cot`; k-steps are 128 half8 apart
+template <int CINP>
+__device__ inline gptr<half8> conv_wrow(const half8 *wp, int cot, int lane)
 {
-    constexpr int CT = COUT / 32, KS = 9 * (CINP / 16);
-    return as_global(wp + ((size_t)(wave % CT) * KS * 64 + lane) * 2);
+    constexpr int KS = 9 * (CINP / 16);
+    return as_global(wp + (size_t)cot * KS * 128 + lane * kWLane);
 }
 
-template <int CINP, int COUT, int RING>
-__device__ inline void conv_preload(const half8 *wp, int wave, int lane, WRing<RING> &r)
+// conv_preload requests the first RING k-steps; it is called well before the layer starts (during
+// the previous layer or the input fill) so that the L2 latency of the first k-steps is not exposed
+// after the barrier that opens the layer.
+template <class G, int CINP, int COUT, int RING, int CW>
+__device__ inline void conv_preload(const half8 *wp, int wave, int lane, WRing<RING, CW> &r)
 {
     constexpr int KS = 9 * (CINP / 16);
     static_assert(RING <= KS, "ring deeper than the layer");
-    const gptr<half8> wrow = conv_wrow<CINP, COUT, RING>(wp, wave, lane);
+    const int cg = wave % ConvSplit<G, COUT, CW>::WC;
 #pragma unroll
-    for (int d = 0; d < RING; d++) { r.ah[d] = wrow[(size_t)d * 128]; r.al[d] = wrow[(size_t)d * 128 + 1]; }
+    for (int c = 0; c < CW; c++) {
+        const gptr<half8> wrow = conv_wrow<CINP>(wp, cg * CW + c, lane);
+#pragma unroll
+        for (int d = 0; d < RING; d++) { r.ah[d][c] = wrow[(size_t)d * 128]; r.al[d][c] = wrow[(size_t)d * 128 + kWLo]; }
+    }
     __builtin_amdgcn_sched_barrier(0);
 }
 
@@ -125,16 +156,18 @@ __device__ inline void conv_preload(const half8 *wp, int wave, int lane, WRing<R
 // halves: 8 hi then 8 lo of W[co = cotile*32 + (lane&31)][ci = cg*16 + 8*(lane>>5) + j].
 // XLO = false skips the w_hi*x_lo term (exact inputs).  xh / xl: hi / lo image
 // ([NP rows + zero row][RS bytes]).  ring: filled by conv_preload for the same layer.
-template <class G, int CINP, int COUT, int RS, bool XLO, bool BPF, int RING, class Prep, class Epi>
-__device__ inline void conv3x3_f16(const half8 *wp, WRing<RING> &ring, const char *xh, const char *xl, int wave,
+// epi(c, cot, tile, acc, prow, ctx) is called for the wave's channel tiles c = 0..CW-1 (global
+// index cot) of every position tile, channel tiles innermost.
+template <class G, int CINP, int COUT, int RS, bool XLO, bool BPF, int RING, int CW, class Prep, class Epi>
+__device__ inline void conv3x3_f16(const half8 *wp, WRing<RING, CW> &ring, const char *xh, const char *xl, int wave,
                                    int lane, Prep prep, Epi epi, Prof *prof = nullptr, int slot = 11)
 {
-    constexpr int CT = COUT / 32;
-    constexpr int WPC = 4 / CT;
-    constexpr int PT = (G::NT + WPC - 1) / WPC;
+    using SP = ConvSplit<G, COUT, CW>;
+    constexpr int PT = SP::PT;
     constexpr int CG = CINP / 16;
     constexpr int KS = 9 * CG;
-    const int sub = wave / CT;
+    const int cg = wave % SP::WC;
+    const int sub = wave / SP::WC;
     const int half = lane >> 5;
     const int j = lane & 31;
     const int zero = G::NP * RS + half * 16;
@@ -162,12 +195,12 @@ __device__ inline void conv3x3_f16(const half8 *wp, WRing<RING> &ring, const cha
         }
     }
     auto addr = [&](int i, int ks) {
-        const int tap = ks / CG, cg = ks - tap * CG;
+        const int tap = ks / CG, cgi = ks - tap * CG;
         const int off = ((tap / 3 - 1) * G::N + (tap % 3 - 1)) * RS;
-        return (((vmask[i] >> tap) & 1u) ? base[i] + off : zero) + cg * 32;
+        return (((vmask[i] >> tap) & 1u) ? base[i] + off : zero) + cgi * 32;
     };
 
-    f32x16 acc[PT];
+    f32x16 acc[CW][PT];
     const f32x16 zacc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (prof && slot != 11) prof->mark(slot - 1);
 
@@ -175,8 +208,13 @@ __device__ inline void conv3x3_f16(const half8 *wp, WRing<RING> &ring, const cha
     // address offset is a compile-time constant: weights (global, L2 resident) run RING
     // k-steps ahead, activations (LDS) one k-step ahead in two register sets, so the MFMAs
     // of a step never wait for a load of that step.
-    const gptr<half8> wrow = conv_wrow<CINP, COUT, RING>(wp, wave, lane);
-    half8 (&ah)[RING] = ring.ah, (&al)[RING] = ring.al;
+    gptr<half8> wrow[CW];
+#pragma unroll
+#ifdef AZG_EXP_SAMECOT           // timing experiment (wrong results): every wave streams channel tile 0 (hits in the vector L1)
+    for (int c = 0; c < CW; c++) wrow[c] = conv_wrow<CINP>(wp, 0, lane);
+#else
+    for (int c = 0; c < CW; c++) wrow[c] = conv_wrow<CINP>(wp, cg * CW + c, lane);
+#endif
     // dense phase: take issue priority over the co-resident workgroup's scalar / f64 tree code
     if (COUT >= 64) __builtin_amdgcn_s_setprio(2);
     // BPF (activation prefetch one k-step ahead) costs 8*PT registers for the second buffer set
@@ -198,30 +236,42 @@ __device__ inline void conv3x3_f16(const half8 *wp, WRing<RING> &ring, const cha
             for (int i = 0; i < PT; i++) {
                 const int a = addr(i, lk);
                 bh[nb][i] = *reinterpret_cast<const half8 *>(xh + a);
+#ifdef AZG_EXP_NOLDSLO          // timing experiment (wrong results): no LDS read of the low halves
+                if (XLO) bl[nb][i] = bh[nb][i];
+#else
                 if (XLO) bl[nb][i] = *reinterpret_cast<const half8 *>(xl + a);
+#endif
             }
         }
-        const half8 wa = ah[ca], wl = al[ca];
-        if (ks + RING < KS) { ah[ca] = wrow[(size_t)(ks + RING) * 128]; al[ca] = wrow[(size_t)(ks + RING) * 128 + 1]; }
+        half8 wa[CW], wl[CW];
 #pragma unroll
-        for (int i = 0; i < PT; i++) {
-            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa, bh[cb][i], ks == 0 ? zacc : acc[i], 0, 0, 0);
-            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, bh[cb][i], acc[i], 0, 0, 0);
-            if (XLO) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa, bl[cb][i], acc[i], 0, 0, 0);
+        for (int c = 0; c < CW; c++) {
+            wa[c] = ring.ah[ca][c]; wl[c] = ring.al[ca][c];
+#ifndef AZG_EXP_NOWLOAD          // timing experiment (wrong results): the weight ring is never refilled
+            if (ks + RING < KS) { ring.ah[ca][c] = wrow[c][(size_t)(ks + RING) * 128]; ring.al[ca][c] = wrow[c][(size_t)(ks + RING) * 128 + kWLo]; }
+#endif
         }
+#pragma unroll
+        for (int i = 0; i < PT; i++)
+#pragma unroll
+            for (int c = 0; c < CW; c++) {
+                acc[c][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[c], bh[cb][i], ks == 0 ? zacc : acc[c][i], 0, 0, 0);
+                acc[c][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[c], bh[cb][i], acc[c][i], 0, 0, 0);
+                if (XLO) acc[c][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[c], bl[cb][i], acc[c][i], 0, 0, 0);
+            }
         // Issue order inside the k-step: the loads of later k-steps and their address
         // arithmetic are spread between this step's MFMAs (an MFMA occupies the matrix pipe for
         // 32 cycles but the issue port for 8).  Left alone the scheduler sinks each load to
         // just before its first use and waits for it there; fenced off as one block in front
         // of the MFMAs they leave the matrix pipe idle while they issue.
         if (BPF) {
-            constexpr int NM = PT * (XLO ? 3 : 2), NDS = PT * (XLO ? 2 : 1);
+            constexpr int NM = CW * PT * (XLO ? 3 : 2), NDS = PT * (XLO ? 2 : 1), NGL = 2 * CW;
 #pragma unroll
             for (int m = 0; m < NM; m++) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                 // one MFMA
                 __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);                 // two VALU (addresses)
                 if (m < NDS) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);    // one LDS read
-                if (m >= NM - 2) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); // one global read
+                if (m >= NM - NGL) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); // one global read
             }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -234,7 +284,9 @@ __device__ inline void conv3x3_f16(const half8 *wp, WRing<RING> &ring, const cha
     const auto ctx = prep();
 #pragma unroll
     for (int i = 0; i < PT; i++)
-        if (sub * PT + i < G::NT) epi(i, sub * PT + i, acc[i], prow[i], ctx);   // wave-uniform: epilogues may use MFMA
+        if (sub * PT + i < G::NT)                              // wave-uniform: epilogues may use MFMA
+#pragma unroll
+            for (int c = 0; c < CW; c++) epi(c, cg * CW + c, sub * PT + i, acc[c][i], prow[i], ctx);
 }
 
 // Wave-wide float reductions on the DPP network (lane^1, lane^2, mirror within 8, mirror within
@@ -269,16 +321,19 @@ __device__ inline float wave_sum_f32(float v)
 // two 8-byte LDS reads) instead of nine k-steps that carry 4 real channels in 16.  No w_hi*x_lo
 // term.  wp: per k-step and lane 8 hi then 8 lo halves of W[co = lane&31][plane = j%4][tap =
 // 4*ks + 2*(lane>>5) + j/4] * 2^8 (zero for tap >= 9).  ring: all three k-steps, preloaded.
-__device__ inline void conv1_preload(const half8 *wp, int lane, WRing<3> &r)
+struct W1Ring {
+    half8 ah[3], al[3];
+};
+__device__ inline void conv1_preload(const half8 *wp, int lane, W1Ring &r)
 {
-    const gptr<half8> wrow = as_global(wp + (size_t)lane * 2);
+    const gptr<half8> wrow = as_global(wp + (size_t)lane * kWLane);
 #pragma unroll
-    for (int d = 0; d < 3; d++) { r.ah[d] = wrow[(size_t)d * 128]; r.al[d] = wrow[(size_t)d * 128 + 1]; }
+    for (int d = 0; d < 3; d++) { r.ah[d] = wrow[(size_t)d * 128]; r.al[d] = wrow[(size_t)d * 128 + kWLo]; }
     __builtin_amdgcn_sched_barrier(0);
 }
 
 template <class G, class Prep, class Epi>
-__device__ inline void conv1_packed_f16(WRing<3> &ring, const char *xin, int wave, int lane, Prep prep, Epi epi, Prof *prof, int slot)
+__device__ inline void conv1_packed_f16(W1Ring &ring, const char *xin, int wave, int lane, Prep prep, Epi epi, Prof *prof, int slot)
 {
     constexpr int RS = G::RS_IN;
     constexpr int PT = (G::NT + 3) / 4;
@@ -363,7 +418,7 @@ __device__ inline void fc16_preload(gptr<half8> w, int ks_total, FcRing<NTG, KW>
 #pragma unroll
     for (int u = 0; u < FcRing<NTG, KW>::RU; u++) {
         const gptr<half8> s = fc16_src<NTG, KW>(w, ks_total, u);
-        r.ah[u] = s[0]; r.al[u] = s[1];
+        r.ah[u] = s[0]; r.al[u] = s[kWLo];
     }
     __builtin_amdgcn_sched_barrier(0);
 }
@@ -393,7 +448,7 @@ __device__ inline void fc16_run(gptr<half8> w, int ks_total, FcRing<NTG, KW> &r,
         const half8 wa = r.ah[u % R::RU], wl = r.al[u % R::RU];
         if (u + R::RU < R::NU) {
             const gptr<half8> s = fc16_src<NTG, KW>(w, ks_total, u + R::RU);
-            r.ah[u % R::RU] = s[0]; r.al[u % R::RU] = s[1];
+            r.ah[u % R::RU] = s[0]; r.al[u % R::RU] = s[kWLo];
         }
         acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh, wa, kk == 0 ? zacc : acc[i], 0, 0, 0);
         acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh, wl, acc[i], 0, 0, 0);
@@ -436,7 +491,7 @@ __device__ inline void cnn16_tail_sparse(const NetWeights &nw, float *lds, int t
             if (k < kmax) {
                 const int cc = k / G::S, cell = k - cc * G::S, c = c0 + cc;
                 const float *pp = lds + G::HP_OFF + c * G::NTP + cell;
-                v = __builtin_fmaf((pp[0] + pp[8 * G::NTP]) + (pp[16 * G::NTP] + pp[24 * G::NTP]), kWUnscale, bh[c]);
+                v = __builtin_fmaf(head_sum(pp, G::NTP), kWUnscale, bh[c]);
             }
             const bool nz = !(v <= 0.0f);                    // a NaN counts as non-zero (see relu_nan)
             const unsigned long long m = __ballot(nz);
@@ -555,8 +610,8 @@ __device__ inline void cnn16_tail(const NetWeights &nw, float *lds, int tid, Pro
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int kgrp = lane >> 4, n = lane & 15;             // FC operand geometry: k group and row / column of the lane
     constexpr int NGP = G::OTP / G::OC;                    // accumulator groups of act_fc1
-    const gptr<half8> wpol = as_global(reinterpret_cast<const half8 *>(nw.wfc16[0])) + ((size_t)wave * G::KWP * 64 + lane) * 2;
-    const gptr<half8> wval = as_global(reinterpret_cast<const half8 *>(nw.wfc16[1])) + ((size_t)wave * G::KWV * 64 + lane) * 2;
+    const gptr<half8> wpol = as_global(reinterpret_cast<const half8 *>(nw.wfc16[0])) + (size_t)wave * G::KWP * 128 + lane * kWLane;
+    const gptr<half8> wval = as_global(reinterpret_cast<const half8 *>(nw.wfc16[1])) + (size_t)wave * G::KWV * 128 + lane * kWLane;
     FcRing<G::OC, G::KWP> rpol;
     FcRing<4, G::KWV> rval;
     fc16_preload<G::OC, G::KWP>(wpol, 4 * G::KWP, rpol);
@@ -580,11 +635,16 @@ __device__ inline void cnn16_tail(const NetWeights &nw, float *lds, int tid, Pro
                     const int c = pol ? cc : 4 + cc, p = leaf * G::S + cell;
                     const float *pp = lds + G::HP_OFF + c * G::NTP + p;
                     const f32x4 p0 = *reinterpret_cast<const f32x4 *>(pp), p1 = *reinterpret_cast<const f32x4 *>(pp + 8 * G::NTP);
-                    const f32x4 p2 = *reinterpret_cast<const f32x4 *>(pp + 16 * G::NTP), p3 = *reinterpret_cast<const f32x4 *>(pp + 24 * G::NTP);
+                    f32x4 ps = {p0[0] + p1[0], p0[1] + p1[1], p0[2] + p1[2], p0[3] + p1[3]};
+                    if (kHeadParts == 4) {
+                        const f32x4 p2 = *reinterpret_cast<const f32x4 *>(pp + 16 * G::NTP), p3 = *reinterpret_cast<const f32x4 *>(pp + 24 * G::NTP);
+#pragma unroll
+                        for (int i = 0; i < 4; i++) ps[i] += p2[i] + p3[i];
+                    }
                     const float b = bh[c];
 #pragma unroll
                     for (int i = 0; i < 4; i++) {
-                        const float v = __builtin_fmaf((p0[i] + p1[i]) + (p2[i] + p3[i]), kWUnscale, b);
+                        const float v = __builtin_fmaf(ps[i], kWUnscale, b);
                         s[i] = relu_nan(v);
                     }
                 }
@@ -606,7 +666,7 @@ __device__ inline void cnn16_tail(const NetWeights &nw, float *lds, int tid, Pro
                 const int cc = k / G::S, cell = k - cc * G::S;
                 const int c = pol ? cc : 4 + cc, p = leaf * G::S + cell;
                 const float *pp = lds + G::HP_OFF + c * G::NTP + p;
-                s = __builtin_fmaf((pp[0] + pp[8 * G::NTP]) + (pp[16 * G::NTP] + pp[24 * G::NTP]), kWUnscale, bh[c]);
+                s = __builtin_fmaf(head_sum(pp, G::NTP), kWUnscale, bh[c]);
                 s = relu_nan(s);
             }
             const _Float16 hi = (_Float16)s;
@@ -698,13 +758,20 @@ __device__ inline void cnn16_forward(const NetWeights &nw_in, float *lds, InputF
     const half8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
 
     const float *lbias = lds + G::BIAS_OFF / 4;            // conv1 | conv2 | conv3 | head biases
-    constexpr int R2 = 6, R3 = 3;                         // k-steps of weights in flight per layer (conv1: all three)
+#ifndef AZG_R2
+#define AZG_R2 (AZG_CW == 2 ? 4 : 6)
+#endif
+#ifndef AZG_R3
+#define AZG_R3 3
+#endif
+    constexpr int R2 = AZG_R2, R3 = AZG_R3;                    // k-steps of weights in flight per layer (conv1: all three)
+    constexpr int CW2 = AZG_CW, CW3 = AZG_CW;
     const half8 *w1 = reinterpret_cast<const half8 *>(nw.w16[0]);
     const half8 *w2 = reinterpret_cast<const half8 *>(nw.w16[1]);
     const half8 *w3 = reinterpret_cast<const half8 *>(nw.w16[2]);
-    WRing<3> ring1;
-    WRing<R2> ring2;
-    WRing<R3> ring3;
+    W1Ring ring1;
+    WRing<R2, CW2> ring2;
+    WRing<R3, CW3> ring3;
     conv1_preload(w1, lane, ring1);
 
     // ---- input image: the 4 planes as halves in channels 0..3 of a 16-channel row; the
@@ -729,24 +796,29 @@ __device__ inline void cnn16_forward(const NetWeights &nw_in, float *lds, InputF
     prof.mark(2);
 
     // epilogue of conv1/conv2: scale back, bias, ReLU, split into halves, store [pos][channel]
-    struct Bias16 { f32x4 b[4]; };
-    auto load_bias = [&](const float *bias, int cobase) {
+    struct Bias16 { f32x4 b[CW2][4]; };
+    // cot0: the wave's first channel tile; nc: channel tiles the wave owns
+    auto load_bias = [&](const float *bias, int cot0, int nc) {
         return [=]() {
             Bias16 c;
 #pragma unroll
-            for (int g = 0; g < 4; g++) c.b[g] = *reinterpret_cast<const f32x4 *>(bias + cobase + 8 * g + 4 * half);
+            for (int t = 0; t < CW2; t++)
+#pragma unroll
+                for (int g = 0; g < 4; g++)
+                    c.b[t][g] = *reinterpret_cast<const f32x4 *>(bias + (cot0 + (t < nc ? t : 0)) * 32 + 8 * g + 4 * half);
             return c;
         };
     };
-    auto store_split = [&](int cobase, char *oh, char *ol, int rs) {
-        return [=](int, int, const f32x16 &acc, int p, const Bias16 &c) {
+    auto store_split = [&](char *oh, char *ol, int rs) {
+        return [=](int ci, int cot, int, const f32x16 &acc, int p, const Bias16 &c) {
             if (G::NP != G::NTP && p < 0) return;           // padding lane of the last tile
+            const int cobase = cot * 32;
 #pragma unroll
             for (int g = 0; g < 4; g++) {
                 half4 h, l;
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
-                    float v = __builtin_fmaf(acc[4 * g + e], kWUnscale, c.b[g][e]);
+                    float v = __builtin_fmaf(acc[4 * g + e], kWUnscale, c.b[ci][g][e]);
                     v = relu_nan(v);
                     const _Float16 hh = (_Float16)v;
                     h[e] = hh;
@@ -758,17 +830,20 @@ __device__ inline void cnn16_forward(const NetWeights &nw_in, float *lds, InputF
             }
         };
     };
-    conv_preload<32, 64, R2>(w2, wave, lane, ring2);
-    conv1_packed_f16<G>(ring1, ldb + G::IN_OFF, wave, lane,
-                        load_bias(lbias, 0), store_split(0, ldb + G::A1H_OFF, ldb + G::A1L_OFF, G::RS_A1), &prof, 13);
+    conv_preload<G, 32, 64, R2, CW2>(w2, wave, lane, ring2);
+    {
+        auto st1 = store_split(ldb + G::A1H_OFF, ldb + G::A1L_OFF, G::RS_A1);
+        conv1_packed_f16<G>(ring1, ldb + G::IN_OFF, wave, lane, load_bias(lbias, 0, 1),
+                            [=](int, int tile, const f32x16 &acc, int p, const Bias16 &c) { st1(0, 0, tile, acc, p, c); }, &prof, 13);
+    }
     prof.mark(16);
     if (tid == 0) gate.acquire();
     __syncthreads();
     prof.mark(3);
-    conv_preload<64, 128, R3>(w3, wave, lane, ring3);
-    conv3x3_f16<G, 32, 64, G::RS_A1, true, G::BPF, R2>(w2, ring2, ldb + G::A1H_OFF, ldb + G::A1L_OFF, wave, lane,
-                                               load_bias(lbias + 32, (wave % 2) * 32),
-                                               store_split((wave % 2) * 32, ldb + G::A2H_OFF, ldb + G::A2L_OFF, G::RS_A2),
+    conv_preload<G, 64, 128, R3, CW3>(w3, wave, lane, ring3);
+    conv3x3_f16<G, 32, 64, G::RS_A1, true, G::BPF, R2, CW2>(w2, ring2, ldb + G::A1H_OFF, ldb + G::A1L_OFF, wave, lane,
+                                               load_bias(lbias + 32, (wave % ConvSplit<G, 64, CW2>::WC) * CW2, CW2),
+                                               store_split(ldb + G::A2H_OFF, ldb + G::A2L_OFF, G::RS_A2),
                                                &prof, 15);
     prof.mark(17);
     __syncthreads();
@@ -779,48 +854,56 @@ __device__ inline void cnn16_forward(const NetWeights &nw_in, float *lds, InputF
     //      1x1 head convolutions (k runs over this wave's 32 channels in accumulator order,
     //      the head weights are packed to match).  The four waves' partial sums meet in LDS.
     {
-        const float *b3 = lbias + 96 + wave * 32;
+        using SP3 = ConvSplit<G, 128, CW3>;
+        const int cg3 = wave % SP3::WC;                    // channel group of this wave: channel tiles cg3*CW3 ..
         // The head tile has 32 rows and 6 head channels: rows 0-7 carry the high halves of the
         // head weights and rows 8-15 the low halves, so ONE instruction per activation half
         // forms both w_hi*x and w_lo*x; adding the two row blocks afterwards gives the full
         // (w_hi + w_lo)(x_hi + x_lo) with two MFMAs per k-step instead of three.
-        struct Head16 { f32x4 b[4]; half8 w[2]; };
-        float *hp = lds + G::HP_OFF + wave * 8 * G::NTP;
-        const char *whp = ldb + G::WH_OFF + ((wave * 4 + half) * 8 + (j < 16 ? (j & 7) : 7)) * 32 + ((j >= 8 && j < 16) ? 16 : 0);
-        conv3x3_f16<G, 64, 128, G::RS_A2, true, G::BPF, R3>(w3, ring3, ldb + G::A2H_OFF, ldb + G::A2L_OFF, wave, lane,
+        struct Head16 { f32x4 b[CW3][4]; half8 w[CW3][2]; };
+        float *hp = lds + G::HP_OFF + cg3 * 8 * G::NTP;
+        f32x16 hd;                                         // head sums of the position tile in work, over the wave's channel tiles
+        conv3x3_f16<G, 64, 128, G::RS_A2, true, G::BPF, R3, CW3>(w3, ring3, ldb + G::A2H_OFF, ldb + G::A2L_OFF, wave, lane,
             [=]() {
                 Head16 c;
 #pragma unroll
-                for (int g = 0; g < 4; g++) c.b[g] = *reinterpret_cast<const f32x4 *>(b3 + 8 * g + 4 * half);
+                for (int t = 0; t < CW3; t++) {
+                    const int cot = cg3 * CW3 + t;
+                    const float *b3 = lbias + 96 + cot * 32;
+                    const char *whp = ldb + G::WH_OFF + ((cot * 4 + half) * 8 + (j < 16 ? (j & 7) : 7)) * 32 + ((j >= 8 && j < 16) ? 16 : 0);
 #pragma unroll
-                for (int s2 = 0; s2 < 2; s2++) c.w[s2] = *reinterpret_cast<const half8 *>(whp + s2 * 512);
+                    for (int g = 0; g < 4; g++) c.b[t][g] = *reinterpret_cast<const f32x4 *>(b3 + 8 * g + 4 * half);
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; s2++) c.w[t][s2] = *reinterpret_cast<const half8 *>(whp + s2 * 512);
+                }
                 return c;
             },
-            [=](int, int tile, const f32x16 &acc, int p, const Head16 &c) {
+            [=, &hd](int ci, int, int tile, const f32x16 &acc, int p, const Head16 &c) {
                 const f32x16 zacc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                f32x16 hd = zacc;
+                if (ci == 0) hd = zacc;
 #pragma unroll
                 for (int s2 = 0; s2 < 2; s2++) {
                     half8 xh8, xl8;
 #pragma unroll
                     for (int e = 0; e < 8; e++) {
                         const int r = 8 * s2 + e;
-                        float v = __builtin_fmaf(acc[r], kWUnscale, c.b[r >> 2][r & 3]);
+                        float v = __builtin_fmaf(acc[r], kWUnscale, c.b[ci][r >> 2][r & 3]);
                         v = relu_nan(v);
                         const _Float16 hh = (_Float16)v;
                         xh8[e] = hh;
                         xl8[e] = (_Float16)(v - (float)hh);
                     }
-                    hd = __builtin_amdgcn_mfma_f32_32x32x16_f16(c.w[s2], xh8, hd, 0, 0, 0);
-                    hd = __builtin_amdgcn_mfma_f32_32x32x16_f16(c.w[s2], xl8, hd, 0, 0, 0);
+                    hd = __builtin_amdgcn_mfma_f32_32x32x16_f16(c.w[ci][s2], xh8, hd, 0, 0, 0);
+                    hd = __builtin_amdgcn_mfma_f32_32x32x16_f16(c.w[ci][s2], xl8, hd, 0, 0, 0);
                 }
+                if (ci != CW3 - 1) return;
                 // rows 0-3 of the head tile sit in registers 0-3 of lanes 0-31, rows 4-7 in
                 // registers 0-3 of lanes 32-63 (rows 6, 7 are zero: their weights are); the
                 // low-half rows 8-15 sit in registers 4-7 of the same lanes
                 if (G::NP != G::NTP && p < 0) return;       // padding lane of the last tile
                 float *dst = hp + (4 * half) * G::NTP + tile * 32 + j;
 #pragma unroll
-                for (int c = 0; c < 4; c++) dst[c * G::NTP] = hd[c] + hd[4 + c];
+                for (int c4 = 0; c4 < 4; c4++) dst[c4 * G::NTP] = hd[c4] + hd[4 + c4];
             }, &prof);
     }
     prof.mark(5);

@@ -11,6 +11,22 @@ constexpr int WAVE = 64;
 constexpr int kStampWords = 32 + 2 * 2048;   // diagnostic counters (see Prof)
 constexpr int kGateWords = 16 * 256;          // (XCC id, SE, SH, CU) -> gate word
 
+// Split-half weight images (convolutions, fully connected layers): a lane's operand of one k-step is
+// 8 high halves and 8 low halves.  Planar (1): per k-step the 64 lanes' high halves are contiguous
+// (1 KB), then the 64 lanes' low halves, so each of the two 16-byte loads of a wave covers eight
+// full 128-byte lines.  Interleaved (0): a lane's high and low halves are adjacent (32 bytes per
+// lane), each load touching half of sixteen lines.
+#ifndef AZG_WPLANAR
+#define AZG_WPLANAR 0
+#endif
+constexpr int kWLo = AZG_WPLANAR ? 64 : 1;        // distance of a lane's low halves from its high halves, in 16-byte units
+constexpr int kWLane = AZG_WPLANAR ? 1 : 2;       // distance between neighbouring lanes, in 16-byte units
+// offset (in halves) of half j (0..7 high, 8..15 low) of `lane` inside one k-step's 1024-half block
+__host__ __device__ inline int wsplit_off(int lane, int j)
+{
+    return AZG_WPLANAR ? ((j >> 3) * 64 + lane) * 8 + (j & 7) : lane * 16 + j;
+}
+
 // Edge meta word: action (cell id) in the low 16 bits, number of children in the high 16.
 __host__ __device__ inline unsigned meta_pack(int act, int k) { return (unsigned)act | ((unsigned)k << 16); }
 __host__ __device__ inline int meta_act(unsigned m) { return (int)(m & 0xFFFFu); }

@@ -203,8 +203,10 @@ __global__ __launch_bounds__(256, (F16 && MODE == 0 && N <= 8) ? AZG_OCC8 : 1) v
     {                                                                                                             \
         search_body<N, T, 0, true>(st);                                                                           \
     }
+#ifndef AZG_ONLY8
 AZG_CAPPED_SEARCH_KERNEL(search_kernel_f16_6x6, 6, 2)
 AZG_CAPPED_SEARCH_KERNEL(search_kernel_f16_7x7, 7, 2)
+#endif
 AZG_CAPPED_SEARCH_KERNEL(search_kernel_f16_8x8, 8, 2)
 #endif
 

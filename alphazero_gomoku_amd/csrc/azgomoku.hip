@@ -252,6 +252,12 @@ static bool pick_search(int N, int mode, int cnn_mode, SearchLaunch *out)
     if (mode == AZG_PRIOR_HASH) { *out = {search_kernel<0, 4, 2, false>, 4, 4 * sizeof(GameLds)}; return true; }
     if (mode == AZG_PRIOR_PEAKED) { *out = {search_kernel<0, 4, 3, false>, 4, 4 * sizeof(GameLds)}; return true; }
     const bool f16 = cnn_mode == AZG_CNN_F16X3;
+#ifdef AZG_ONLY8                 // experiment builds: the 8x8 split-f16 kernels only (compiles in a third of the time)
+    if (N != 8 || !f16) return false;
+    *out = net_launch<8, AZG_T8, true>();
+    out->fn = search_kernel_f16_8x8;
+    return true;
+#else
     switch (N) {
     case 6: *out = f16 ? net_launch<6, 2, true>() : net_launch<6, 2, false>(); break;
     case 8: *out = f16 ? net_launch<8, AZG_T8, true>() : net_launch<8, 2, false>(); break;
@@ -274,6 +280,7 @@ static bool pick_search(int N, int mode, int cnn_mode, SearchLaunch *out)
     if (f16 && N == 8) out->fn = search_kernel_f16_8x8;
 #endif
     return true;
+#endif
 }
 
 struct EvalLaunch {
@@ -292,6 +299,11 @@ static EvalLaunch eval_launch()
 static bool pick_eval(int N, int cnn_mode, EvalLaunch *out)
 {
     const bool f16 = cnn_mode == AZG_CNN_F16X3;
+#ifdef AZG_ONLY8
+    if (N != 8 || !f16) return false;
+    *out = eval_launch<8, 2, true>();
+    return true;
+#else
     switch (N) {
     case 6: *out = f16 ? eval_launch<6, 2, true>() : eval_launch<6, 2, false>(); return true;
     case 8: *out = f16 ? eval_launch<8, 2, true>() : eval_launch<8, 2, false>(); return true;
@@ -306,6 +318,7 @@ static bool pick_eval(int N, int cnn_mode, EvalLaunch *out)
     case 16: if (!f16) return false; *out = eval_launch<16, 1, true>(); return true;
     default: return false;
     }
+#endif
 }
 
 // ---------------------------------------------------------------- mirrors / profiling
@@ -543,13 +556,13 @@ static void pack_conv16(const float *w, int cin, int cinp, int cout, _Float16 *o
             for (int lane = 0; lane < 64; lane++) {
                 const int tap = ks / CG, cg = ks % CG;
                 const int co = cot * 32 + (lane & 31);
-                _Float16 *dst = out + (((size_t)cot * KS + ks) * 64 + lane) * 16;
+                _Float16 *dst = out + ((size_t)cot * KS + ks) * 1024;
                 for (int j = 0; j < 8; j++) {
                     const int ci = cg * 16 + 8 * (lane >> 5) + j;
                     const float v = ci < cin ? w[((size_t)co * cin + ci) * 9 + tap] * kWScale : 0.0f;
                     const _Float16 hi = (_Float16)v;
-                    dst[j] = hi;
-                    dst[8 + j] = (_Float16)(v - (float)hi);
+                    dst[wsplit_off(lane, j)] = hi;
+                    dst[wsplit_off(lane, 8 + j)] = (_Float16)(v - (float)hi);
                 }
             }
 }
@@ -562,13 +575,13 @@ static void pack_conv1_16(const float *w /*[32][4][3][3]*/, _Float16 *out)
     for (int ks = 0; ks < 3; ks++)
         for (int lane = 0; lane < 64; lane++) {
             const int co = lane & 31;
-            _Float16 *dst = out + ((size_t)ks * 64 + lane) * 16;
+            _Float16 *dst = out + (size_t)ks * 1024;
             for (int j = 0; j < 8; j++) {
                 const int tap = 4 * ks + 2 * (lane >> 5) + j / 4, ci = j % 4;
                 const float v = tap < 9 ? w[((size_t)co * 4 + ci) * 9 + tap] * kWScale : 0.0f;
                 const _Float16 hi = (_Float16)v;
-                dst[j] = hi;
-                dst[8 + j] = (_Float16)(v - (float)hi);
+                dst[wsplit_off(lane, j)] = hi;
+                dst[wsplit_off(lane, 8 + j)] = (_Float16)(v - (float)hi);
             }
         }
 }
@@ -583,13 +596,13 @@ static void pack_fc16(const float *w, int O, int K, int otiles, int ksteps, _Flo
         for (int ks = 0; ks < ksteps; ks++)
             for (int lane = 0; lane < 64; lane++) {
                 const int o = ot * 16 + (lane & 15);
-                _Float16 *dst = out + (((size_t)ot * ksteps + ks) * 64 + lane) * 16;
+                _Float16 *dst = out + ((size_t)ot * ksteps + ks) * 1024;
                 for (int j = 0; j < 8; j++) {
                     const int k = ks * 32 + 8 * (lane >> 4) + j;
                     const float v = (o < O && k < K) ? w[(size_t)o * K + k] * kWScale : 0.0f;
                     const _Float16 hi = (_Float16)v;
-                    dst[j] = hi;
-                    dst[8 + j] = (_Float16)(v - (float)hi);
+                    dst[wsplit_off(lane, j)] = hi;
+                    dst[wsplit_off(lane, 8 + j)] = (_Float16)(v - (float)hi);
                 }
             }
 }
