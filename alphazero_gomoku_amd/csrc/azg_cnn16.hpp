@@ -33,15 +33,26 @@ typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 // returning numbers computed from clipped activations.
 __device__ inline float relu_nan(float v) { return v < 0.0f ? 0.0f : v; }
 
-#ifndef AZG_CW
-#define AZG_CW 1            // output-channel tiles per wave in conv2 / conv3 (see ConvSplit)
+// Output-channel tiles per wave in conv2 / conv3 (see ConvSplit): one for the two-leaf kernels, two
+// for the one-leaf kernels (boards above 8x8: eight position tiles, whose accumulators would not fit
+// beside the operands in the 256 registers a wave has when eight waves share a CU).  Every kernel of
+// a board size -- search, evaluation -- uses the same value: the grouping of the head convolutions'
+// partial sums follows it, and a position must evaluate to the same bits wherever it is evaluated.
+#ifndef AZG_CW1
+#define AZG_CW1 2
 #endif
-constexpr int kHeadParts = 4 / AZG_CW;      // partial sums of the head convolutions per position (one per channel group of conv3)
-// sum of a position's head partials (kHeadParts blocks of 8 rows, ntp floats per row, apart)
+#ifndef AZG_CW2
+#define AZG_CW2 1
+#endif
+template <class G>
+struct ConvWaves { static constexpr int CW = G::T == 1 ? AZG_CW1 : AZG_CW2, HPARTS = 4 / CW; };
+// sum of a position's PARTS head partials (blocks of 8 rows, ntp floats per row, apart)
+template <int PARTS>
 __device__ inline float head_sum(const float *pp, int ntp)
 {
-    if (kHeadParts == 4) return (pp[0] + pp[8 * ntp]) + (pp[16 * ntp] + pp[24 * ntp]);
-    return pp[0] + pp[8 * ntp];
+    if (PARTS == 4) return (pp[0] + pp[8 * ntp]) + (pp[16 * ntp] + pp[24 * ntp]);
+    if (PARTS == 2) return pp[0] + pp[8 * ntp];
+    return pp[0];
 }
 
 constexpr float kWScale = 256.0f;            // weights are stored as half(w * 2^8)
@@ -491,7 +502,7 @@ __device__ inline void cnn16_tail_sparse(const NetWeights &nw, float *lds, int t
             if (k < kmax) {
                 const int cc = k / G::S, cell = k - cc * G::S, c = c0 + cc;
                 const float *pp = lds + G::HP_OFF + c * G::NTP + cell;
-                v = __builtin_fmaf(head_sum(pp, G::NTP), kWUnscale, bh[c]);
+                v = __builtin_fmaf(head_sum<ConvWaves<G>::HPARTS>(pp, G::NTP), kWUnscale, bh[c]);
             }
             const bool nz = !(v <= 0.0f);                    // a NaN counts as non-zero (see relu_nan)
             const unsigned long long m = __ballot(nz);
@@ -636,10 +647,10 @@ __device__ inline void cnn16_tail(const NetWeights &nw, float *lds, int tid, Pro
                     const float *pp = lds + G::HP_OFF + c * G::NTP + p;
                     const f32x4 p0 = *reinterpret_cast<const f32x4 *>(pp), p1 = *reinterpret_cast<const f32x4 *>(pp + 8 * G::NTP);
                     f32x4 ps = {p0[0] + p1[0], p0[1] + p1[1], p0[2] + p1[2], p0[3] + p1[3]};
-                    if (kHeadParts == 4) {
+                    if (ConvWaves<G>::HPARTS == 4) {
                         const f32x4 p2 = *reinterpret_cast<const f32x4 *>(pp + 16 * G::NTP), p3 = *reinterpret_cast<const f32x4 *>(pp + 24 * G::NTP);
 #pragma unroll
-                        for (int i = 0; i < 4; i++) ps[i] += p2[i] + p3[i];
+                        for (int i = 0; i < 4; i++) ps[i] = ps[i] + (p2[i] + p3[i]);
                     }
                     const float b = bh[c];
 #pragma unroll
@@ -666,7 +677,7 @@ __device__ inline void cnn16_tail(const NetWeights &nw, float *lds, int tid, Pro
                 const int cc = k / G::S, cell = k - cc * G::S;
                 const int c = pol ? cc : 4 + cc, p = leaf * G::S + cell;
                 const float *pp = lds + G::HP_OFF + c * G::NTP + p;
-                s = __builtin_fmaf(head_sum(pp, G::NTP), kWUnscale, bh[c]);
+                s = __builtin_fmaf(head_sum<ConvWaves<G>::HPARTS>(pp, G::NTP), kWUnscale, bh[c]);
                 s = relu_nan(s);
             }
             const _Float16 hi = (_Float16)s;
@@ -759,13 +770,13 @@ __device__ inline void cnn16_forward(const NetWeights &nw_in, float *lds, InputF
 
     const float *lbias = lds + G::BIAS_OFF / 4;            // conv1 | conv2 | conv3 | head biases
 #ifndef AZG_R2
-#define AZG_R2 (AZG_CW == 2 ? 4 : 6)
+#define AZG_R2 6
 #endif
 #ifndef AZG_R3
 #define AZG_R3 3
 #endif
-    constexpr int R2 = AZG_R2, R3 = AZG_R3;                    // k-steps of weights in flight per layer (conv1: all three)
-    constexpr int CW2 = AZG_CW, CW3 = AZG_CW;
+    constexpr int R2 = ConvWaves<G>::CW == 2 ? 4 : AZG_R2, R3 = AZG_R3;                    // k-steps of weights in flight per layer (conv1: all three)
+    constexpr int CW2 = ConvWaves<G>::CW, CW3 = ConvWaves<G>::CW;
     const half8 *w1 = reinterpret_cast<const half8 *>(nw.w16[0]);
     const half8 *w2 = reinterpret_cast<const half8 *>(nw.w16[1]);
     const half8 *w3 = reinterpret_cast<const half8 *>(nw.w16[2]);

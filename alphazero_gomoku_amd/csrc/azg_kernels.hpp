@@ -6,6 +6,7 @@
 
 #include "azg_cnn16.hpp"
 #include "azg_tree.hpp"
+#include "azg_dual.hpp"
 
 namespace azg {
 
@@ -203,11 +204,13 @@ __global__ __launch_bounds__(256, (F16 && MODE == 0 && N <= 8) ? AZG_OCC8 : 1) v
     {                                                                                                             \
         search_body<N, T, 0, true>(st);                                                                           \
     }
-#ifndef AZG_ONLY8
+#if !defined(AZG_ONLY8) && !defined(AZG_ONLY15)
 AZG_CAPPED_SEARCH_KERNEL(search_kernel_f16_6x6, 6, 2)
 AZG_CAPPED_SEARCH_KERNEL(search_kernel_f16_7x7, 7, 2)
 #endif
+#ifndef AZG_ONLY15
 AZG_CAPPED_SEARCH_KERNEL(search_kernel_f16_8x8, 8, 2)
+#endif
 #endif
 
 // ---------------------------------------------------------------- one playout, evaluated by the host

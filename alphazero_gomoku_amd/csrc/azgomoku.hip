@@ -232,9 +232,17 @@ static int scratch_get(azg_handle *h, int slot, size_t bytes, void **out)
 // ---------------------------------------------------------------- kernel dispatch
 struct SearchLaunch {
     void (*fn)(DevState);
-    int T;
+    int T;                  // games per workgroup
     size_t lds;
+    int threads = 256;
 };
+
+// Two wave groups per workgroup (azg_dual.hpp): TS games per set, two sets.
+template <int N, int TS>
+static SearchLaunch dual_launch()
+{
+    return {search_dual_kernel<N, TS>, 2 * TS, (size_t)DualGeom<N, TS>::TOTAL * 4, 512};
+}
 
 template <int N, int T, bool F16>
 static SearchLaunch net_launch()
@@ -243,6 +251,9 @@ static SearchLaunch net_launch()
     return {search_kernel<N, T, 0, F16>, T, (size_t)G::END * 4 + T * sizeof(GameLdsT<N * N + 1>)};
 }
 
+#ifndef AZG_DUAL
+#define AZG_DUAL 1      // boards of 9x9 .. 15x15: the kernel with two wave groups per workgroup (azg_dual.hpp)
+#endif
 #ifndef AZG_T8
 #define AZG_T8 2        // games per workgroup of the split-f16 8x8 search kernel
 #endif
@@ -257,19 +268,23 @@ static bool pick_search(int N, int mode, int cnn_mode, SearchLaunch *out)
     *out = net_launch<8, AZG_T8, true>();
     out->fn = search_kernel_f16_8x8;
     return true;
+#elif defined(AZG_ONLY15)        // experiment builds: 15x15 only
+    if (N != 15 || !f16) return false;
+    *out = AZG_DUAL ? dual_launch<15, 1>() : net_launch<15, 1, true>();
+    return true;
 #else
     switch (N) {
     case 6: *out = f16 ? net_launch<6, 2, true>() : net_launch<6, 2, false>(); break;
     case 8: *out = f16 ? net_launch<8, AZG_T8, true>() : net_launch<8, 2, false>(); break;
-    case 15: *out = f16 ? net_launch<15, 1, true>() : net_launch<15, 1, false>(); break;
+    case 15: *out = f16 ? (AZG_DUAL ? dual_launch<15, 1>() : net_launch<15, 1, true>()) : net_launch<15, 1, false>(); break;
     // the other board sizes: split-f16 arithmetic only
     case 7: if (!f16) return false; *out = net_launch<7, 2, true>(); break;
-    case 9: if (!f16) return false; *out = net_launch<9, 1, true>(); break;
-    case 10: if (!f16) return false; *out = net_launch<10, 1, true>(); break;
-    case 11: if (!f16) return false; *out = net_launch<11, 1, true>(); break;
-    case 12: if (!f16) return false; *out = net_launch<12, 1, true>(); break;
-    case 13: if (!f16) return false; *out = net_launch<13, 1, true>(); break;
-    case 14: if (!f16) return false; *out = net_launch<14, 1, true>(); break;
+    case 9: if (!f16) return false; *out = AZG_DUAL ? dual_launch<9, 1>() : net_launch<9, 1, true>(); break;
+    case 10: if (!f16) return false; *out = AZG_DUAL ? dual_launch<10, 1>() : net_launch<10, 1, true>(); break;
+    case 11: if (!f16) return false; *out = AZG_DUAL ? dual_launch<11, 1>() : net_launch<11, 1, true>(); break;
+    case 12: if (!f16) return false; *out = AZG_DUAL ? dual_launch<12, 1>() : net_launch<12, 1, true>(); break;
+    case 13: if (!f16) return false; *out = AZG_DUAL ? dual_launch<13, 1>() : net_launch<13, 1, true>(); break;
+    case 14: if (!f16) return false; *out = AZG_DUAL ? dual_launch<14, 1>() : net_launch<14, 1, true>(); break;
     case 16: if (!f16) return false; *out = net_launch<16, 1, true>(); break;
     default: return false;
     }
@@ -302,6 +317,10 @@ static bool pick_eval(int N, int cnn_mode, EvalLaunch *out)
 #ifdef AZG_ONLY8
     if (N != 8 || !f16) return false;
     *out = eval_launch<8, 2, true>();
+    return true;
+#elif defined(AZG_ONLY15)
+    if (N != 15 || !f16) return false;
+    *out = eval_launch<15, 1, true>();
     return true;
 #else
     switch (N) {
@@ -372,6 +391,7 @@ static int mirrors_unpack(azg_handle *h)
     for (int g = 0; g < B; g++) {
         if (h->h_err[g] & 1) return fail(h, AZG_EARENA, "slot %d: search tree outgrew its arena (arena_nodes=%d)", g, h->cfg.arena_nodes);
         if (h->h_err[g] & 2) return fail(h, AZG_EMOVE, "slot %d: illegal move", g);
+        if (h->h_err[g] & 8) return fail(h, AZG_EHIP, "slot %d: the wave groups of the search kernel lost step (a wait ran out)", g);
         if (h->h_err[g] & 4) return fail(h, AZG_ERANGE, "slot %d: an activation of the net left the half-precision range "
                                          "(|x| > 65504) in the split-f16 convolutions; create the engine with AZG_CNN_F32", g);
     }
@@ -809,7 +829,7 @@ extern "C" int azg_search(azg_handle *h)
     }
     auto &ev = h->ev_pool[h->ev_pending];
     HIPCHK(h, hipEventRecord(ev.first, h->stream));
-    hipLaunchKernelGGL(sl.fn, dim3(grid), dim3(256), sl.lds, h->stream, h->st);
+    hipLaunchKernelGGL(sl.fn, dim3(grid), dim3(sl.threads), sl.lds, h->stream, h->st);
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipEventRecord(ev.second, h->stream));
     h->ev_pending++;
@@ -1483,6 +1503,16 @@ extern "C" int azg_arena_stats(azg_handle *h, int64_t *moved_to_large, int64_t *
     if (trees_dropped) *trees_dropped = (int64_t)v[1];
     return AZG_OK;
 }
+
+#ifdef AZG_DUAL_DUMP
+extern "C" int azg_debug_dual_dump(azg_handle *h, float *out)
+{
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dual_dump), sizeof(float) * 256 * 2048));
+    return AZG_OK;
+}
+#endif
 
 extern "C" int azg_host_timing(azg_handle *h, double *noise_ms, int64_t *noise_steps)
 {

@@ -2,6 +2,10 @@
 # Builds libazgomoku.so for gfx950 (MI355X).
 #  -ffp-contract=off keeps the PUCT and running-mean arithmetic in the reference's operation
 #   order (no fused multiply-add).
+#  -fno-slp-vectorize keeps float32 arithmetic on single-lane VALU instructions.  Left on, -O3 packs
+#   adjacent multiply-adds into v_pk_fma_f32; in the kernel whose tree waves share their SIMDs with
+#   matrix-dense waves (azg_dual.hpp) such packed results came out one term short in lanes 48-63 of
+#   the low halves (measured: 98 of 256 identical searches differed, none without packing).
 #  -no-hip-rt leaves the HIP runtime symbols undefined: the process must hold exactly ONE HIP
 #   runtime, and PyTorch ships its own libamdhip64.so.  The loader (alphazero_gomoku_amd/_lib.py)
 #   loads the runtime PyTorch will use (or /opt/rocm's when PyTorch is absent) with RTLD_GLOBAL
@@ -10,7 +14,7 @@ set -e
 here="$(cd "$(dirname "$0")" && pwd)"
 out="$here/../libazgomoku.so"
 log="$(mktemp)"
-hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared -std=c++17 -Wall -no-hip-rt \
+hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fno-slp-vectorize -fPIC -shared -std=c++17 -Wall -no-hip-rt \
     -Rpass-analysis=kernel-resource-usage \
     "$here/azgomoku.hip" -o "$out" -lpthread "$@" 2> "$log" || { cat "$log" >&2; rm -f "$log"; exit 1; }
 # compiler warnings, without the resource-usage remarks and their source excerpts

@@ -7,7 +7,7 @@ name="$1"; shift
 mkdir -p "$here/../../abx"
 out="$here/../../abx/libazg_$name.so"
 log="$here/../../abx/build_$name.log"
-hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared -std=c++17 -no-hip-rt -DAZG_ONLY8 \
+hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fno-slp-vectorize -fPIC -shared -std=c++17 -no-hip-rt -DAZG_ONLY8 \
     -Rpass-analysis=kernel-resource-usage "$here/azgomoku.hip" -o "$out" -lpthread "$@" 2> "$log" || { tail -30 "$log" >&2; exit 1; }
 grep -A12 "Function Name: _ZN3azg21search_kernel_f16_8x8" "$log" | grep -E "VGPRs:|Spill|LDS Size|Occupancy" | sed "s/^.*remark: [^ ]* //" | tr '\n' ' '
 echo " -> $out"

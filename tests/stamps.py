@@ -25,7 +25,8 @@ for _ in range(4):
 eng.L.azg_debug_stamps(eng.h, out)
 l, ms, ev = eng.profile()
 names = ["select+end", "sync->cnn", "fill", "conv1", "conv2", "conv3+heads", "sync", "headsum", "fc", "softmax", "expand+backup", "conv3 k-loop", "conv1 setup", "conv1 k-loop", "conv2 setup", "conv2 k-loop", "conv1 epilogue", "conv2 epilogue"]
-ngroups = (B + 1) // 2 if n <= 8 else B          # workgroups per launch
+ngroups = (B + 1) // 2 if (n <= 8 or os.environ.get("DUAL")) else B          # workgroups per launch
+per_group = 4 if n <= 8 else (2 if os.environ.get("DUAL") else 1)             # playouts per workgroup iteration
 raw = list(out)
 out = [v / ngroups for v in out]
 tot = sum(out[:20])

@@ -918,3 +918,44 @@ def test_cnn_and_net_search_on_every_board_size(az, oracle, n):
     assert np.array_equal(visits[0][acts], ovis) and np.array_equal(q[0][acts], oq) and np.array_equal(p[0][acts], op), n
     eng.close()
     ev.close()
+
+
+@pytest.mark.parametrize("n,B", [(15, 5), (9, 4), (12, 3)])
+def test_two_wave_group_search_kernel_with_both_sets_live(az, oracle, n, B):
+    """Boards from 9x9 to 15x15 are searched by the kernel whose workgroups hold two games and two
+    wave groups (net waves / tree waves, hand-over through LDS counters).  Several games, so that
+    both sets of a workgroup are live and (odd B) one workgroup has a dead set; three plies with
+    tree re-use; visits, Q and priors bit-equal to the oracle's tree (mcts_alphaZero.py:113-148)
+    fed the evaluation kernel's own outputs -- the two kernels must agree to the bit."""
+    k, npo = 5, 96
+    params = helpers.make_params(n, seed=100 + n)
+    eng = az.SelfPlayEngine(n, k, npo, B)
+    eng.set_weights(params)
+    ev = az.SelfPlayEngine(n, k, 1, 1)
+    ev.set_weights(params)
+    eng.reset_games(seeds=np.arange(B, dtype=np.uint32) + 5)
+
+    def policy(b):
+        ob = oracle.OracleBoard(n, n, k)
+        ob.b = b
+        pr, v = ev.eval_batch(ob.current_state().astype(np.float32))
+        return [float(x) for x in pr[0]], float(v[0])
+    trees = [oracle.OracleMCTS(policy, c_puct=5, n_playout=npo) for _ in range(B)]
+    boards = []
+    for g in range(B):
+        ob = oracle.OracleBoard(n, n, k)
+        ob.init_board()
+        boards.append(ob)
+    for ply in range(3):
+        eng.search()
+        visits, q, p, rn = eng.root_stats()
+        moves, _ = eng.sample_and_advance(1.0, want_pi=False)
+        for g in range(B):
+            acts, ovis, oq, op, _ = trees[g].get_move_probs(boards[g], temp=1.0)
+            assert rn[g] == trees[g].root_visits(), (ply, g)
+            assert np.array_equal(visits[g][acts], ovis), (ply, g)
+            assert np.array_equal(q[g][acts], oq) and np.array_equal(p[g][acts], op), (ply, g)
+            trees[g].update_with_move(int(moves[g]))
+            boards[g].do_move(int(moves[g]))
+    eng.close()
+    ev.close()
