@@ -33,6 +33,23 @@ typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 // returning numbers computed from clipped activations.
 __device__ inline float relu_nan(float v) { return v < 0.0f ? 0.0f : v; }
 
+// Two float32 values as split-f16 pairs: h = half(v), l = half(v - h), packed (v0 in the low
+// halves).  One packed conversion gives h; v_fma_mix{lo,hi}_f16 then takes a HALF of h as a source,
+// widens it exactly, forms h * -1.0 + v in float32 (exact: the difference has at most 13 significant
+// bits) and rounds once to f16 -- bit for bit what (half)(v - (float)h) computes in three instructions
+// (checked on the GPU over 2^23 pairs including denormal, infinite and NaN inputs).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ inline void split2_f16(float v0, float v1, unsigned &h, unsigned &l)
+{
+    const f32x2 v = {v0, v1};
+    h = __builtin_bit_cast(unsigned, __builtin_convertvector(v, half2v));
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l) : "v"(h), "v"(v0));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l) : "v"(h), "v"(v1));
+}
+
 // Output-channel tiles per wave in conv2 / conv3 (see ConvSplit): one for the two-leaf kernels, two
 // for the one-leaf kernels (boards above 8x8: eight position tiles, whose accumulators would not fit
 // beside the operands in the 256 registers a wave has when eight waves share a CU).  Every kernel of
@@ -65,7 +82,12 @@ struct Cnn16Geom {
     static constexpr int NT = (NP + 31) / 32;
     static constexpr int NTP = NT * 32;
     static constexpr int ROWS = NP + 1;                       // + the all-zero row
-    static constexpr bool BPF = true;                         // explicit LDS prefetch (costs 8 registers per tile)
+    // activation (LDS) prefetch of the 3x3 layers: 0 none, 1 one k-step ahead (two register sets of
+    // all the wave's position tiles), 2 one position tile ahead (two sets of ONE tile)
+#ifndef AZG_BPF
+#define AZG_BPF 1
+#endif
+    static constexpr int BPF = AZG_BPF;
     // row strides in bytes (channels * 2 + 16 pad)
     static constexpr int RS_IN = 16 * 2 + 16, RS_A1 = 32 * 2 + 16, RS_A2 = 64 * 2 + 16;
     // LDS map in bytes
@@ -167,9 +189,10 @@ __device__ inline void conv_preload(const half8 *wp, int wave, int lane, WRing<R
 // halves: 8 hi then 8 lo of W[co = cotile*32 + (lane&31)][ci = cg*16 + 8*(lane>>5) + j].
 // XLO = false skips the w_hi*x_lo term (exact inputs).  xh / xl: hi / lo image
 // ([NP rows + zero row][RS bytes]).  ring: filled by conv_preload for the same layer.
+// KEEP_PRIO: the caller's waves hold the raised issue priority for their whole life.
 // epi(c, cot, tile, acc, prow, ctx) is called for the wave's channel tiles c = 0..CW-1 (global
 // index cot) of every position tile, channel tiles innermost.
-template <class G, int CINP, int COUT, int RS, bool XLO, bool BPF, int RING, int CW, class Prep, class Epi>
+template <class G, int CINP, int COUT, int RS, bool XLO, int BPF, int RING, int CW, bool KEEP_PRIO = false, class Prep, class Epi>
 __device__ inline void conv3x3_f16(const half8 *wp, WRing<RING, CW> &ring, const char *xh, const char *xl, int wave,
                                    int lane, Prep prep, Epi epi, Prof *prof = nullptr, int slot = 11)
 {
@@ -228,6 +251,48 @@ __device__ inline void conv3x3_f16(const half8 *wp, WRing<RING, CW> &ring, const
 #endif
     // dense phase: take issue priority over the co-resident workgroup's scalar / f64 tree code
     if (COUT >= 64) __builtin_amdgcn_s_setprio(2);
+    if constexpr (BPF == 2) {
+        // Activations one POSITION TILE ahead: the steps n = ks * PT + i form one sequence; the LDS
+        // reads of step n + 1 are issued behind the first MFMAs of step n (CW * 3 MFMAs, 32 cycles
+        // each, cover the LDS latency), into the register set step n - 1 used.
+        half8 bh[2], bl[2];
+        auto load = [&](int n, int buf) {
+            const int a = addr(n % PT, n / PT);
+            bh[buf] = *reinterpret_cast<const half8 *>(xh + a);
+            if (XLO) bl[buf] = *reinterpret_cast<const half8 *>(xl + a);
+        };
+        load(0, 0);
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) {
+            const int ca = ks % RING;
+            half8 wa[CW], wl[CW];
+#pragma unroll
+            for (int c = 0; c < CW; c++) {
+                wa[c] = ring.ah[ca][c]; wl[c] = ring.al[ca][c];
+                if (ks + RING < KS) { ring.ah[ca][c] = wrow[c][(size_t)(ks + RING) * 128]; ring.al[ca][c] = wrow[c][(size_t)(ks + RING) * 128 + kWLo]; }
+            }
+#pragma unroll
+            for (int i = 0; i < PT; i++) {
+                const int n = ks * PT + i, cb = n & 1;
+                if (n + 1 < KS * PT) load(n + 1, cb ^ 1);
+#pragma unroll
+                for (int c = 0; c < CW; c++) {
+                    acc[c][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[c], bh[cb], ks == 0 ? zacc : acc[c][i], 0, 0, 0);
+                    acc[c][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[c], bh[cb], acc[c][i], 0, 0, 0);
+                    if (XLO) acc[c][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[c], bl[cb], acc[c][i], 0, 0, 0);
+                }
+                constexpr int NM = CW * (XLO ? 3 : 2), NDS = XLO ? 2 : 1, NGL = 2 * CW;
+#pragma unroll
+                for (int m = 0; m < NM; m++) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                 // one MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);                 // two VALU (addresses)
+                    if (m < NDS) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);    // one LDS read
+                    if (i == 0 && m >= NM - (NGL < NM ? NGL : NM)) __builtin_amdgcn_sched_group_barrier(0x020, NGL <= NM ? 1 : 2, 0);   // the k-step's weight loads
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    } else {
     // BPF (activation prefetch one k-step ahead) costs 8*PT registers for the second buffer set
     constexpr int NB = BPF ? 2 : 1;
     half8 bh[NB][PT], bl[NB][PT];
@@ -287,7 +352,8 @@ __device__ inline void conv3x3_f16(const half8 *wp, WRing<RING, CW> &ring, const
         }
         __builtin_amdgcn_sched_barrier(0);
     }
-    if (COUT >= 64) __builtin_amdgcn_s_setprio(0);
+    }
+    if (COUT >= 64 && !KEEP_PRIO) __builtin_amdgcn_s_setprio(0);
     if (prof) prof->mark(slot);
     // prep() reads what every tile's epilogue needs from LDS once, before the first epilogue
     // store (the compiler must assume a later read could alias such a store and would
@@ -826,18 +892,19 @@ __device__ inline void cnn16_forward(const NetWeights &nw_in, float *lds, InputF
             const int cobase = cot * 32;
 #pragma unroll
             for (int g = 0; g < 4; g++) {
-                half4 h, l;
+                u32x2 h, l;
 #pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    float v = __builtin_fmaf(acc[4 * g + e], kWUnscale, c.b[ci][g][e]);
-                    v = relu_nan(v);
-                    const _Float16 hh = (_Float16)v;
+                for (int e = 0; e < 2; e++) {
+                    const float v0 = relu_nan(__builtin_fmaf(acc[4 * g + 2 * e], kWUnscale, c.b[ci][g][2 * e]));
+                    const float v1 = relu_nan(__builtin_fmaf(acc[4 * g + 2 * e + 1], kWUnscale, c.b[ci][g][2 * e + 1]));
+                    unsigned hh, ll;
+                    split2_f16(v0, v1, hh, ll);
                     h[e] = hh;
-                    l[e] = (_Float16)(v - (float)hh);
+                    l[e] = ll;
                 }
                 const int off = p * rs + (cobase + 8 * g + 4 * half) * 2;
-                *reinterpret_cast<half4 *>(oh + off) = h;
-                *reinterpret_cast<half4 *>(ol + off) = l;
+                *reinterpret_cast<u32x2 *>(oh + off) = h;
+                *reinterpret_cast<u32x2 *>(ol + off) = l;
             }
         };
     };
@@ -894,16 +961,18 @@ __device__ inline void cnn16_forward(const NetWeights &nw_in, float *lds, InputF
                 if (ci == 0) hd = zacc;
 #pragma unroll
                 for (int s2 = 0; s2 < 2; s2++) {
-                    half8 xh8, xl8;
+                    u32x4 xh4, xl4;
 #pragma unroll
-                    for (int e = 0; e < 8; e++) {
-                        const int r = 8 * s2 + e;
-                        float v = __builtin_fmaf(acc[r], kWUnscale, c.b[ci][r >> 2][r & 3]);
-                        v = relu_nan(v);
-                        const _Float16 hh = (_Float16)v;
-                        xh8[e] = hh;
-                        xl8[e] = (_Float16)(v - (float)hh);
+                    for (int e = 0; e < 4; e++) {
+                        const int r = 8 * s2 + 2 * e;
+                        const float v0 = relu_nan(__builtin_fmaf(acc[r], kWUnscale, c.b[ci][r >> 2][r & 3]));
+                        const float v1 = relu_nan(__builtin_fmaf(acc[r + 1], kWUnscale, c.b[ci][(r + 1) >> 2][(r + 1) & 3]));
+                        unsigned hh, ll;
+                        split2_f16(v0, v1, hh, ll);
+                        xh4[e] = hh;
+                        xl4[e] = ll;
                     }
+                    const half8 xh8 = __builtin_bit_cast(half8, xh4), xl8 = __builtin_bit_cast(half8, xl4);
                     hd = __builtin_amdgcn_mfma_f32_32x32x16_f16(c.w[ci][s2], xh8, hd, 0, 0, 0);
                     hd = __builtin_amdgcn_mfma_f32_32x32x16_f16(c.w[ci][s2], xl8, hd, 0, 0, 0);
                 }

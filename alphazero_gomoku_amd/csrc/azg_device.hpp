@@ -128,9 +128,9 @@ struct Prof {
     static constexpr int GETREG_HW_ID = 4 | (0 << 6) | (31 << 11), GETREG_XCC_ID = 20 | (0 << 6) | (3 << 11);
     long long *out; long long last, t0, r0; bool on;
     unsigned acc[20];
-    __device__ void start(long long *o)
+    __device__ void start(long long *o, int tid_on = 0)
     {
-        out = o; on = o != nullptr && threadIdx.x == 0;
+        out = o; on = o != nullptr && (int)threadIdx.x == tid_on;
         for (int i = 0; i < 20; i++) acc[i] = 0;
         last = t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime();
     }
@@ -149,7 +149,7 @@ struct Prof {
         }
     }
 #else
-    __device__ void start(long long *) {}
+    __device__ void start(long long *, int = 0) {}
     __device__ void mark(int) {}
     __device__ void finish() {}
 #endif

@@ -5,11 +5,13 @@
 // batch of leaves leaves the matrix pipes idle during select / expand / backup / softmax and the tree
 // waves idle during the convolutions.  Here a workgroup owns two SETS of T games and two groups of
 // four waves:
-//   net waves  (0-3): conv1, conv2, conv3 + head convolutions -- for the set whose leaves are
-//                     ready, then for the other set, and so on;
+//   net waves  (0-3): conv2, conv3 + head convolutions -- for the set whose leaf is ready, then
+//                     for the other set, and so on;
 //   tree waves (4-7): fully connected layers + softmax / tanh of the evaluated set, expand, backup,
-//                     the next descent, the input planes of the new leaves -- while the net waves
-//                     work on the other set.
+//                     the next descent, the input planes of the new leaf and conv1 on them -- while
+//                     the net waves work on the other set.
+// conv1's output image exists once: the net waves count the conv2 layers they have finished
+// (a1gen), and the tree waves start the n-th conv1 only after n-1 of them.
 // The groups never meet at the hardware barrier (it would join all eight waves): each has its own
 // software barrier, and batches travel through two LDS counters per set (req: leaves handed over,
 // ack: evaluations finished).  Both groups visit the sets strictly in turn, every turn of the tree
@@ -33,7 +35,8 @@ struct DualCtl {
     unsigned ack[2];         // per set: batches evaluated
     unsigned fin[2];         // per set: no further batch will come
     unsigned abort;          // a wait ran out
-    unsigned pad[7];
+    unsigned a1gen;          // conv2 layers finished by the net waves (each frees conv1's output image)
+    unsigned pad[6];
 };
 
 __device__ inline unsigned lds_load(const unsigned *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
@@ -79,6 +82,20 @@ __device__ inline unsigned wait_change(const unsigned *word, unsigned seen, cons
     return v;
 }
 
+// wait until *word >= want (counters that only grow); false: the workgroup is being abandoned
+__device__ inline bool wait_ge(const unsigned *word, unsigned want, unsigned *abort_word)
+{
+    bool ok = false;
+    for (int spin = 0; spin < kSpinLimit; spin++) {
+        if ((int)(lds_load(word) - want) >= 0) { ok = true; break; }
+        if (lds_load(abort_word)) break;
+        __builtin_amdgcn_s_sleep(2);
+    }
+    if (!ok) lds_store(abort_word, 1u);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    return ok;
+}
+
 template <int N_, int T_>
 struct DualGeom : Cnn16Geom<N_, T_> {
     using G = Cnn16Geom<N_, T_>;
@@ -114,15 +131,115 @@ struct DualGeom : Cnn16Geom<N_, T_> {
     __device__ static char *in_image(float *lds, int set) { return reinterpret_cast<char *>(lds + (set ? IN1_OFF : 0)) + (set ? 0 : G::IN_OFF); }
 };
 
-// ---------------------------------------------------------------- net waves
-// conv1 .. head convolutions of one leaf; xin: the set's input image, tl: the set's hand-over
-// region.  The body follows cnn16_forward (azg_cnn16.hpp) with the group's barriers and without the
-// matrix gate (there is no second dense workgroup on the CU).  conv3's epilogue ADDS each wave's
-// head sums into tl[TX_OFF..] with LDS float atomics: every element gets exactly two addends (one
-// per channel group of conv3) on top of the zero the tree waves left there, so the result does not
-// depend on the order of arrival and equals the partial-sum addition of the one-workgroup kernels.
+// ---------------------------------------------------------------- convolution layers
+#ifndef AZG_DUAL_BPF3
+#define AZG_DUAL_BPF3 0      // conv3 of the dual kernels: LDS prefetch mode of conv3x3_f16 (2 measured 1 % slower: the tree waves bound the pair)
+#endif
+#ifndef AZG_DUAL_PRIO
+#define AZG_DUAL_PRIO 2      // issue priority of the net waves (the critical path; they share their SIMDs with the tree waves)
+#endif
+#ifndef AZG_DUAL_R3
+#define AZG_DUAL_R3 2
+#endif
+#ifndef AZG_FC_NT
+#define AZG_FC_NT 0          // 1: the sparse FC reads its weight rows with the non-temporal hint
+#endif
+#if AZG_FC_NT
+#define AZG_FC_LOAD(p) __builtin_nontemporal_load(p)
+#else
+#define AZG_FC_LOAD(p) (*(p))
+#endif
+
+// bias values of a wave's channel tiles, as the accumulator layout of v_mfma_f32_32x32x16 wants them
+template <int CW>
+struct Bias16 { f32x4 b[CW][4]; };
+
+template <int CW>
+struct LoadBias {
+    const float *bias; int cot0, nc, half;
+    __device__ Bias16<CW> operator()() const
+    {
+        Bias16<CW> c;
+#pragma unroll
+        for (int t = 0; t < CW; t++)
+#pragma unroll
+            for (int g = 0; g < 4; g++)
+                c.b[t][g] = *reinterpret_cast<const f32x4 *>(bias + (cot0 + (t < nc ? t : 0)) * 32 + 8 * g + 4 * half);
+        return c;
+    }
+};
+
+// epilogue of conv1 / conv2: bias, ReLU, split into f16 pairs, store to the hi / lo images
+template <class G, int CW>
+struct StoreSplit {
+    char *oh, *ol; int rs, half;
+    __device__ void operator()(int ci, int cot, int, const f32x16 &acc, int p, const Bias16<CW> &c) const
+    {
+        if (G::NP != G::NTP && p < 0) return;
+        const int cobase = cot * 32;
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            u32x2 h, l;
+#pragma unroll
+            for (int e = 0; e < 2; e++) {
+                const float v0 = relu_nan(__builtin_fmaf(acc[4 * g + 2 * e], kWUnscale, c.b[ci][g][2 * e]));
+                const float v1 = relu_nan(__builtin_fmaf(acc[4 * g + 2 * e + 1], kWUnscale, c.b[ci][g][2 * e + 1]));
+                unsigned hh, ll;
+                split2_f16(v0, v1, hh, ll);
+                h[e] = hh;
+                l[e] = ll;
+            }
+            const int off = p * rs + (cobase + 8 * g + 4 * half) * 2;
+            *reinterpret_cast<u32x2 *>(oh + off) = h;
+            *reinterpret_cast<u32x2 *>(ol + off) = l;
+        }
+    }
+};
+
+// conv1 of one leaf, run by the TREE waves (wave4 = 0..3) from the set's input image into the one
+// conv1 output image; the caller has waited until the net waves are done with that image.
 template <class D>
-__device__ inline bool dual_front(const NetWeights &nw_in, float *lds, const char *xin, float *tl, GroupSync &gs, Prof &prof)
+__device__ inline void dual_conv1(const NetWeights &nw_in, float *lds, const char *xin, int wave4, int lane)
+{
+    using G = typename D::G;
+    const NetWeights nw = opaque_weights(nw_in);
+    char *ldb = reinterpret_cast<char *>(lds);
+    constexpr int CW = ConvWaves<G>::CW;
+    const float *lbias = lds + G::BIAS_OFF / 4;
+    W1Ring ring1;
+    conv1_preload(reinterpret_cast<const half8 *>(nw.w16[0]), lane, ring1);
+    const StoreSplit<G, CW> st1 = {ldb + G::A1H_OFF, ldb + G::A1L_OFF, G::RS_A1, lane >> 5};
+    conv1_packed_f16<G>(ring1, xin, wave4, lane, LoadBias<CW>{lbias, 0, 1, lane >> 5},
+                        [=](int, int tile, const f32x16 &acc, int p, const Bias16<CW> &c) { st1(0, 0, tile, acc, p, c); }, nullptr, 13);
+}
+
+template <class D>
+struct DualRings {
+    WRing<3, ConvWaves<typename D::G>::CW> ring2;
+};
+
+// the first k-steps of conv2's weights: requested before the net waves wait for a leaf
+template <class D>
+__device__ inline void dual_preload(const NetWeights &nw_in, DualRings<D> &r)
+{
+    using G = typename D::G;
+    const NetWeights nw = opaque_weights(nw_in);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    conv_preload<G, 32, 64, 3, ConvWaves<G>::CW>(reinterpret_cast<const half8 *>(nw.w16[1]), wave, lane, r.ring2);
+}
+
+// ---------------------------------------------------------------- net waves
+// conv2, conv3 and the head convolutions of one leaf whose conv1 output the tree waves have left in
+// the A1 images; tl: the set's hand-over region.  The body follows cnn16_forward (azg_cnn16.hpp) with
+// the group's barriers and without the matrix gate (there is no second dense workgroup on the CU).
+// conv3's epilogue ADDS each wave's head sums into tl[TX_OFF..] with LDS float atomics: every element
+// gets exactly two addends (one per channel group of conv3) on top of the zero the tree waves left
+// there, so the result does not depend on the order of arrival and equals the partial-sum addition of
+// the one-workgroup kernels.  rings.ring2 comes in loaded (dual_preload) and leaves loaded for the
+// next leaf.  a1gen / a1count: see DualCtl.
+template <class D>
+__device__ inline bool dual_front(const NetWeights &nw_in, float *lds, float *tl, DualRings<D> &rings, unsigned *a1gen, unsigned &a1count,
+                                  GroupSync &gs, Prof &prof)
 {
     using G = typename D::G;
     const NetWeights nw = opaque_weights(nw_in);
@@ -135,70 +252,19 @@ __device__ inline bool dual_front(const NetWeights &nw_in, float *lds, const cha
     const float *lbias = lds + G::BIAS_OFF / 4;
     constexpr int CW = ConvWaves<G>::CW;
     static_assert(ConvWaves<G>::HPARTS == 2, "two addends per head sum: the order of the atomic additions must not matter");
-#ifndef AZG_DUAL_BPF3
-#define AZG_DUAL_BPF3 0      // conv3 of the dual kernels: activations prefetched one k-step ahead (a second register set)
-#endif
-#ifndef AZG_DUAL_R3
-#define AZG_DUAL_R3 2
-#endif
     constexpr int R2 = 3, R3 = AZG_DUAL_R3;
-    constexpr bool BPF3 = AZG_DUAL_BPF3 != 0;
-    const half8 *w1 = reinterpret_cast<const half8 *>(nw.w16[0]);
+    constexpr int BPF3 = AZG_DUAL_BPF3;
     const half8 *w2 = reinterpret_cast<const half8 *>(nw.w16[1]);
     const half8 *w3 = reinterpret_cast<const half8 *>(nw.w16[2]);
-    W1Ring ring1;
-    WRing<R2, CW> ring2;
     WRing<R3, CW> ring3;
-    conv1_preload(w1, lane, ring1);
-
-    struct Bias16 { f32x4 b[CW][4]; };
-    auto load_bias = [&](const float *bias, int cot0, int nc) {
-        return [=]() {
-            Bias16 c;
-#pragma unroll
-            for (int t = 0; t < CW; t++)
-#pragma unroll
-                for (int g = 0; g < 4; g++)
-                    c.b[t][g] = *reinterpret_cast<const f32x4 *>(bias + (cot0 + (t < nc ? t : 0)) * 32 + 8 * g + 4 * half);
-            return c;
-        };
-    };
-    auto store_split = [&](char *oh, char *ol, int rs) {
-        return [=](int ci, int cot, int, const f32x16 &acc, int p, const Bias16 &c) {
-            if (G::NP != G::NTP && p < 0) return;
-            const int cobase = cot * 32;
-#pragma unroll
-            for (int g = 0; g < 4; g++) {
-                half4 h, l;
-#pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    float v = __builtin_fmaf(acc[4 * g + e], kWUnscale, c.b[ci][g][e]);
-                    v = relu_nan(v);
-                    const _Float16 hh = (_Float16)v;
-                    h[e] = hh;
-                    l[e] = (_Float16)(v - (float)hh);
-                }
-                const int off = p * rs + (cobase + 8 * g + 4 * half) * 2;
-                *reinterpret_cast<half4 *>(oh + off) = h;
-                *reinterpret_cast<half4 *>(ol + off) = l;
-            }
-        };
-    };
-    conv_preload<G, 32, 64, R2, CW>(w2, wave, lane, ring2);
-    {
-        auto st1 = store_split(ldb + G::A1H_OFF, ldb + G::A1L_OFF, G::RS_A1);
-        conv1_packed_f16<G>(ring1, xin, wave, lane, load_bias(lbias, 0, 1),
-                            [=](int, int tile, const f32x16 &acc, int p, const Bias16 &c) { st1(0, 0, tile, acc, p, c); }, &prof, 13);
-    }
-    prof.mark(16);
-    if (!gs.sync()) return false;
-    prof.mark(3);
     conv_preload<G, 64, 128, R3, CW>(w3, wave, lane, ring3);
-    conv3x3_f16<G, 32, 64, G::RS_A1, true, G::BPF, R2, CW>(w2, ring2, ldb + G::A1H_OFF, ldb + G::A1L_OFF, wave, lane,
-                                                          load_bias(lbias + 32, (wave % ConvSplit<G, 64, CW>::WC) * CW, CW),
-                                                          store_split(ldb + G::A2H_OFF, ldb + G::A2L_OFF, G::RS_A2), &prof, 15);
+    conv3x3_f16<G, 32, 64, G::RS_A1, true, G::BPF, R2, CW, AZG_DUAL_PRIO != 0>(w2, rings.ring2, ldb + G::A1H_OFF, ldb + G::A1L_OFF, wave, lane,
+        LoadBias<CW>{lbias + 32, (wave % ConvSplit<G, 64, CW>::WC) * CW, CW, half},
+        StoreSplit<G, CW>{ldb + G::A2H_OFF, ldb + G::A2L_OFF, G::RS_A2, half}, &prof, 15);
     prof.mark(17);
     if (!gs.sync()) return false;
+    a1count++;
+    if (tid == 0) lds_store(a1gen, a1count);           // every net wave is done with conv1's output
     prof.mark(4);
     {
         using SP3 = ConvSplit<G, 128, CW>;
@@ -206,7 +272,7 @@ __device__ inline bool dual_front(const NetWeights &nw_in, float *lds, const cha
         struct Head16 { f32x4 b[CW][4]; half8 w[CW][2]; };
         float *hx = tl + D::TX_OFF;
         f32x16 hd;
-        conv3x3_f16<G, 64, 128, G::RS_A2, true, BPF3, R3, CW>(w3, ring3, ldb + G::A2H_OFF, ldb + G::A2L_OFF, wave, lane,
+        conv3x3_f16<G, 64, 128, G::RS_A2, true, BPF3, R3, CW, AZG_DUAL_PRIO != 0>(w3, ring3, ldb + G::A2H_OFF, ldb + G::A2L_OFF, wave, lane,
             [=]() {
                 Head16 c;
 #pragma unroll
@@ -226,16 +292,18 @@ __device__ inline bool dual_front(const NetWeights &nw_in, float *lds, const cha
                 if (ci == 0) hd = zacc;
 #pragma unroll
                 for (int s2 = 0; s2 < 2; s2++) {
-                    half8 xh8, xl8;
+                    u32x4 xh4, xl4;
 #pragma unroll
-                    for (int e = 0; e < 8; e++) {
-                        const int r = 8 * s2 + e;
-                        float v = __builtin_fmaf(acc[r], kWUnscale, c.b[ci][r >> 2][r & 3]);
-                        v = relu_nan(v);
-                        const _Float16 hh = (_Float16)v;
-                        xh8[e] = hh;
-                        xl8[e] = (_Float16)(v - (float)hh);
+                    for (int e = 0; e < 4; e++) {
+                        const int r = 8 * s2 + 2 * e;
+                        const float v0 = relu_nan(__builtin_fmaf(acc[r], kWUnscale, c.b[ci][r >> 2][r & 3]));
+                        const float v1 = relu_nan(__builtin_fmaf(acc[r + 1], kWUnscale, c.b[ci][(r + 1) >> 2][(r + 1) & 3]));
+                        unsigned hh, ll;
+                        split2_f16(v0, v1, hh, ll);
+                        xh4[e] = hh;
+                        xl4[e] = ll;
                     }
+                    const half8 xh8 = __builtin_bit_cast(half8, xh4), xl8 = __builtin_bit_cast(half8, xl4);
                     hd = __builtin_amdgcn_mfma_f32_32x32x16_f16(c.w[ci][s2], xh8, hd, 0, 0, 0);
                     hd = __builtin_amdgcn_mfma_f32_32x32x16_f16(c.w[ci][s2], xl8, hd, 0, 0, 0);
                 }
@@ -249,6 +317,7 @@ __device__ inline bool dual_front(const NetWeights &nw_in, float *lds, const cha
             }, &prof);
     }
     prof.mark(5);
+    conv_preload<G, 32, 64, R2, CW>(w2, wave, lane, rings.ring2);      // conv2's first weights for the next leaf
     return gs.sync();                      // every net wave's additions are in
 }
 
@@ -294,6 +363,11 @@ __device__ inline bool dual_tail(const NetWeights &nw_in, float *lds, float *tl,
     const int np = compact(4 * G::S, 0, lp);
     const int nv = compact(2 * G::S, 4, lv);
     wave_sync();                                              // the lists are read back by this wave only
+    prof.mark(18);
+    // Both layers stream one weight row per non-zero input from L2; the tree waves' loads share the
+    // CU's vector-memory path with the conv weights of the net waves.  (Keeping the loads of the next
+    // block of rows in flight while one block is multiplied was measured 4 % SLOWER: the bursts
+    // delay the net waves' weight stream.)
     {
         const gptr<f32x4> wrow = as_global(reinterpret_cast<const f32x4 *>(nw.wpfc_k)) + lane;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -305,7 +379,7 @@ __device__ inline bool dual_tail(const NetWeights &nw_in, float *lds, float *tl,
             for (int u = 0; u < U; u++) {
                 const Pair e = lp[i0 + u < np ? i0 + u : np - 1];
                 xv[u] = i0 + u < np ? e.x : 0.0f;
-                wv[u] = wrow[(size_t)e.k * 64];
+                wv[u] = AZG_FC_LOAD(wrow + (size_t)e.k * 64);
             }
 #pragma unroll
             for (int u = 0; u < U; u++)
@@ -315,6 +389,7 @@ __device__ inline bool dual_tail(const NetWeights &nw_in, float *lds, float *tl,
         wave_sync();                                          // the policy list is dead: its place takes the sums
         *reinterpret_cast<f32x4 *>(yw + 4 * lane) = acc;
     }
+    prof.mark(19);
     {
         const int grp = lane >> 4, l16 = lane & 15;
         const gptr<f32x4> wrow = as_global(reinterpret_cast<const f32x4 *>(nw.wvfc1_k)) + l16;
@@ -327,7 +402,7 @@ __device__ inline bool dual_tail(const NetWeights &nw_in, float *lds, float *tl,
                 const int i = i0 + 4 * u + grp;
                 const Pair e = lv[i < nv ? i : nv - 1];
                 xv[u] = i < nv ? e.x : 0.0f;
-                wv[u] = wrow[(size_t)e.k * 16];
+                wv[u] = AZG_FC_LOAD(wrow + (size_t)e.k * 16);
             }
 #pragma unroll
             for (int u = 0; u < 8; u++)
@@ -337,6 +412,7 @@ __device__ inline bool dual_tail(const NetWeights &nw_in, float *lds, float *tl,
         wave_sync();                                          // both lists are dead now
         *reinterpret_cast<f32x4 *>(yw + 256 + grp * 64 + 4 * l16) = acc;
     }
+    prof.mark(3);
     if (!gs.sync()) return false;
     prof.mark(8);
     if (wave == 0) {
@@ -451,12 +527,16 @@ __device__ __forceinline__ void search_dual_body(DevState st)
     GroupSync gs;
     gs.init(&ctl->bar[net_group ? 0 : 1], &ctl->abort);
     Prof prof;
-    prof.start(net_group ? st.stamps : nullptr);
+    prof.start(st.stamps, net_group ? 0 : 256);       // diagnostic builds: thread 0 times the net waves, thread 256 the tree waves
 
     if (net_group) {
-        // ---- net waves: serve the sets in turn
-        unsigned served[2] = {0, 0};
+        // ---- net waves: serve the sets in turn.  They are the critical path of the workgroup and
+        // share their SIMDs with the tree waves: issue priority for everything they do.
+        if (AZG_DUAL_PRIO) __builtin_amdgcn_s_setprio(AZG_DUAL_PRIO);
+        unsigned served[2] = {0, 0}, a1count = 0;
         bool over[2] = {false, false};
+        DualRings<D> rings;
+        dual_preload<D>(st.net, rings);
         while (!(over[0] && over[1])) {
 #pragma unroll
             for (int s = 0; s < 2; s++) {
@@ -465,7 +545,7 @@ __device__ __forceinline__ void search_dual_body(DevState st)
                 if (lds_load(&ctl->abort)) return;
                 if (r == served[s]) { over[s] = true; continue; }          // fin: no batch will follow
                 prof.mark(1);
-                if (!dual_front<D>(st.net, smem, D::in_image(smem, s), smem + D::TL_OFF + s * D::TL_WORDS, gs, prof)) return;
+                if (!dual_front<D>(st.net, smem, smem + D::TL_OFF + s * D::TL_WORDS, rings, &ctl->a1gen, a1count, gs, prof)) return;
                 served[s]++;
                 if (tid == 0) lds_store(&ctl->ack[s], served[s]);
                 prof.mark(10);
@@ -483,7 +563,7 @@ __device__ __forceinline__ void search_dual_body(DevState st)
 #pragma unroll
     for (int s = 0; s < 2; s++)
         if (!gls[s].live) it[s] = st.n_playout;              // nothing to search: the set only reports "no more batches"
-    unsigned reqs[2] = {0, 0};
+    unsigned reqs[2] = {0, 0}, n_conv1 = 0;
     long long n_eval[2] = {0, 0};
     while (!(over[0] && over[1])) {
 #pragma unroll
@@ -497,6 +577,7 @@ __device__ __forceinline__ void search_dual_body(DevState st)
                 // the evaluation of this set's leaf: wait for the net waves, then FC + softmax here
                 const unsigned a = wait_change(&ctl->ack[s], reqs[s] - 1, nullptr, &ctl->abort);
                 if (lds_load(&ctl->abort) || a != reqs[s]) { lds_store(&ctl->abort, 1u); break; }
+                prof.mark(0);
                 if (!dual_tail<D>(st.net, smem, tl, tid4, gs, prof)) break;
 #ifdef AZG_DUAL_DUMP
                 if (it[s] == 0 && gl->gid < 256)
@@ -516,6 +597,7 @@ __device__ __forceinline__ void search_dual_body(DevState st)
                 }
                 it[s]++;
                 pending[s] = false;
+                prof.mark(2);
             }
             bool broke = false;
             while (it[s] < st.n_playout) {
@@ -533,10 +615,19 @@ __device__ __forceinline__ void search_dual_body(DevState st)
                     n_eval[s] += term == 0;
                 }
                 if (!gs.sync()) { broke = true; break; }
+                prof.mark(6);
                 if (gl->live && gl->need_eval) {
-                    // the leaf goes to the net waves: its input planes first (all four tree waves)
+                    // the leaf goes to the net waves: its input planes and conv1 first (all four tree
+                    // waves), conv1 as soon as the net waves have read the previous conv1 output
                     dual_fill_input<D>(D::in_image(smem, s), gl, tid4);
                     if (!gs.sync()) { broke = true; break; }
+                    prof.mark(7);
+                    if (!wait_ge(&ctl->a1gen, n_conv1, &ctl->abort)) { broke = true; break; }
+                    prof.mark(12);
+                    dual_conv1<D>(st.net, smem, D::in_image(smem, s), wave4, lane);
+                    n_conv1++;
+                    if (!gs.sync()) { broke = true; break; }
+                    prof.mark(13);
                     reqs[s]++;
                     if (tid4 == 0) lds_store(&ctl->req[s], reqs[s]);
                     pending[s] = true;
@@ -551,6 +642,7 @@ __device__ __forceinline__ void search_dual_body(DevState st)
                 }
                 it[s]++;
                 if (!gs.sync()) { broke = true; break; }        // need_eval / term are rewritten by the next descent
+                prof.mark(16);
             }
             if (broke) break;
             if (!pending[s] && it[s] >= st.n_playout) {
@@ -560,6 +652,7 @@ __device__ __forceinline__ void search_dual_body(DevState st)
         }
         if (lds_load(&ctl->abort)) break;
     }
+    prof.finish();
     if (lds_load(&ctl->abort)) {
         // a wait ran out: the net waves may be anywhere; flag every slot of the workgroup
         for (int t = 0; t < D::NG; t++)

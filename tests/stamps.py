@@ -7,7 +7,7 @@ import helpers
 import alphazero_gomoku_amd as az
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 8
-eng = az.SelfPlayEngine(n, 5, 400 if n == 8 else 200, B, cnn_mode=int(os.environ.get("CNN_MODE", "0")))
+eng = az.SelfPlayEngine(n, 5, int(os.environ.get("PLAYOUTS", 400 if n == 8 else 200)), B, cnn_mode=int(os.environ.get("CNN_MODE", "0")))
 eng.set_weights(helpers.make_params(n, seed=100 + n))
 from alphazero_gomoku_amd.engine import SelfPlayRunner
 run = SelfPlayRunner(eng, temp=1.0, seed0=0, total=None, on_samples=None, device_samples=False)
@@ -32,6 +32,21 @@ out = [v / ngroups for v in out]
 tot = sum(out[:20])
 print("launches", l, "ms/launch", ms / l, "cycles/playout", tot / (4 * eng.n_playout),
       "clock GHz", out[30] / max(1, out[31]) * 0.1)
+if os.environ.get("DUAL"):
+    # two-wave-group kernel: thread 0 stamps the net waves, thread 256 the tree waves; per leaf evaluation
+    names = {1: "net: wait for a leaf", 14: "net: conv2 setup", 15: "net: conv2 k-loop", 17: "net: conv2 epilogue", 4: "net: sync + a1gen",
+             11: "net: conv3 k-loop", 5: "net: conv3 epilogue + heads", 10: "net: preload + sync + ack",
+             0: "tree: wait for the net", 18: "tree: head sums -> lists", 19: "tree: policy FC", 3: "tree: value FC", 8: "tree: sync after FC", 9: "tree: softmax + sync", 2: "tree: expand + backup", 6: "tree: select + end test",
+             7: "tree: input planes", 12: "tree: wait for A1", 13: "tree: conv1", 16: "tree: terminal backup"}
+    ev_per_group = ev / l / ngroups if l else 1
+    print("evaluations per workgroup and launch %.0f" % ev_per_group)
+    for grp in ("net", "tree"):
+        tot_g = sum(raw[i] for i, nm in names.items() if nm.startswith(grp)) / ngroups / l / ev_per_group
+        print("%s waves: %.0f cycles per evaluation" % (grp, tot_g))
+        for i, nm in names.items():
+            if nm.startswith(grp):
+                print("  %-30s %8.0f" % (nm, raw[i] / ngroups / l / ev_per_group))
+    names = []
 for i, nm in enumerate(names):
     print("%-14s %8.0f cyc/playout  %5.1f%%" % (nm, out[i] / (4 * eng.n_playout), 100.0 * out[i] / tot))
 wg = np.array(raw[32:32 + 2 * ngroups], dtype=np.int64).reshape(-1, 2)
