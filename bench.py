@@ -31,13 +31,15 @@ REFERENCE_PYTHON_GAMES_PER_S = {(8, 400): 0.0290, (6, 200): 0.1165}
 
 
 def pmc_traffic(cnn, n, playouts, games):
-    """HBM bytes per search launch from the newest committed rocprofv3 --pmc summary of the default
-    workload (profiles/*pmc_search_kernel*.json: FETCH_SIZE and WRITE_SIZE from separate passes, in
-    KiB).  None for any other workload or when no summary travels with the tree."""
+    """HBM bytes per search launch from the newest committed rocprofv3 --pmc summary of this
+    workload (profiles/r*_pmc_search_kernel.json for the default 8x8 workload, ..._c4.json for
+    15x15/800/512: FETCH_SIZE and WRITE_SIZE from separate passes, in KiB).  None for any other
+    workload or when no summary travels with the tree."""
     import glob
-    if (cnn, n, playouts, games) != ("f16x3", 8, 400, 1024):
+    tag = {("f16x3", 8, 400, 1024): "", ("f16x3", 15, 800, 512): "_c4"}.get((cnn, n, playouts, games))
+    if tag is None:
         return None, None
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_search_kernel*.json")),
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_search_kernel%s.json" % tag)),
                    key=lambda f: (len(os.path.basename(f).split("_")[0]), os.path.basename(f)))
     for f in reversed(files):
         try:
@@ -281,14 +283,16 @@ def main():
             "value_from_plies": (args.games * world / (plies_per_game * dt / args.steps)) if plies_per_game else None,
             "playouts_per_s": evals / dt, "samples_gathered": gathered,
             "host_noise_ms_per_step": host[0] / host[1] if host[1] else None,
-            "roofline": {"bound": "mfma", "kernel": "search_kernel (fused select + leaf CNN + expand + backup)",
+            "roofline": {"bound": "mfma", "kernel": ("search_dual_kernel (net waves: conv2 + conv3 + heads; tree waves: select, conv1, FC, expand, backup)"
+                                                 if 9 <= n <= 15 and args.cnn == "f16x3" else
+                                                 "search_kernel (fused select + leaf CNN + expand + backup)"),
                          "achieved": achieved, "peak": PEAK_TFLOPS[args.cnn], "unit": "TFLOP/s",
                          "frac": achieved / PEAK_TFLOPS[args.cnn],
                          "traffic": traffic, "traffic_source": traffic_src,
                          "traffic_note": "HBM bytes per launch, (FETCH_SIZE + WRITE_SIZE) * 1024 of separate rocprofv3 --pmc "
                                          "passes; the tree arrays move as 4-8 B per lane accesses, for which gfx950's FETCH_SIZE "
                                          "is uncalibrated (it halves 16 B per lane streams): the read share may be up to 2x larger",
-                         "note": "achieved counts the ALGORITHMIC flops of the leaf CNN (12.09 MFLOP per evaluation at 8x8); "
+                         "note": "achieved counts the ALGORITHMIC flops of the leaf CNN (flop_per_leaf_eval, 12.09 MFLOP at 8x8); "
                                  "the f16x3 path issues ~2.9x that many MFMA flops",
                          "launches": launches, "avg_launch_ms": kernel_ms / launches if launches else None,
                          "flop_per_leaf_eval": flop, "leaf_evals_per_launch": evals_per_gpu / launches if launches else None},

@@ -1,0 +1,25 @@
+#!/bin/bash
+# Runs on the GPU box (through gpurun): rocprofv3 kernel statistics and separate counter passes of
+# bench.py for one workload.  usage: profiles/profile_gpu.sh TAG [bench.py arguments ...]
+# Leaves gpurun_out/TAG_{bench_under_rocprof.json,kernel_stats.csv,pmc_search_kernel.json}.
+# Every step has its own time limit; the first failure ends the script.
+set -e -o pipefail
+tag="$1"; shift
+root="$(cd "$(dirname "$0")/.." && pwd)"
+out="$root/gpurun_out"
+mkdir -p "$out"
+export TMPDIR=/tmp
+cd "$root"
+rm -rf "$out/prof_${tag}"*
+timeout -s KILL 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/prof_${tag}_stats" -o run -- python3 bench.py --no-cpu-baseline "$@" \
+    > "$out/${tag}_bench_under_rocprof.json" 2> "$out/${tag}_stats.err"
+stats="$(find "$out/prof_${tag}_stats" -name '*kernel_stats.csv' | head -1)"
+cp "$stats" "$out/${tag}_kernel_stats.csv"
+for pass in FETCH_SIZE WRITE_SIZE "SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES"; do
+    name="$(echo "$pass" | cut -d' ' -f1)"
+    timeout -s KILL 400 rocprofv3 --pmc $pass --output-format csv -d "$out/prof_${tag}_pmc_$name" -o run -- python3 bench.py --no-cpu-baseline "$@" --preroll-max 40 --steps 8 --warmup 2 \
+        > "$out/${tag}_pmc_$name.json" 2> "$out/${tag}_pmc_$name.err"
+done
+python3 tests/pmc_summary.py "$out/${tag}_pmc_search_kernel.json" "$out/prof_${tag}_pmc_"* > /dev/null
+head -3 "$out/${tag}_kernel_stats.csv"
+cat "$out/${tag}_pmc_search_kernel.json"

@@ -18,7 +18,7 @@ def main():
             per = defaultdict(lambda: defaultdict(float))          # counter -> dispatch -> value
             with open(path, newline="") as f:
                 for row in csv.DictReader(f):
-                    if "search_kernel" not in row["Kernel_Name"]:
+                    if "search_" not in row["Kernel_Name"]:            # search_kernel*, search_dual_kernel
                         continue
                     per[row["Counter_Name"]][int(row["Dispatch_Id"])] += float(row["Counter_Value"])
             for name, by_dispatch in per.items():
