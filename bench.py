@@ -26,7 +26,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 FLOP_PER_EVAL = {6: 6.79e6, 8: 12.09e6, 15: 42.80e6}    # 188416*S + 8*S*S + 128, 2 flop / MAC
 PEAK_TFLOPS = {"f16x3": 2500.0, "f32": 157.3}            # dense MFMA peaks of MI355X: f16 inputs / f32 inputs
 # the reference's own Python path (mcts_alphaZero.py + policy_value_net_numpy.py), one thread, measured
-# where the reference could be imported (another box): games/s at the per-game settings
+# where the reference could be imported (the build container, not the GPU box): games/s at the per-game settings
 REFERENCE_PYTHON_GAMES_PER_S = {(8, 400): 0.0290, (6, 200): 0.1165}
 
 
