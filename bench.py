@@ -194,13 +194,32 @@ def main():
                             cnn_mode=az._lib.CNN_F16X3 if args.cnn == "f16x3" else az._lib.CNN_F32)
     eng.set_weights(params)
     drained = []
+    # sharded runs exchange the tuples in their packed form (stone words instead of planes: one byte
+    # buffer per rank); the pipelined runner delivers them that way
+    packed = use_dist and not args.host_refill
     run = SelfPlayRunner(eng, temp=1.0, seed0=0, first_game_id=rank, game_id_stride=world,
-                         total=None, on_samples=drained.append, device_samples=True, pipelined=not args.host_refill)
+                         total=None, on_samples=drained.append, device_samples=True, pipelined=not args.host_refill,
+                         packed_samples=packed)
     run.start()
 
     def gather_all(chunks):
         # the (state, pi, z) gather of the sharded configuration: every rank ends up with every
-        # rank's tuples (RCCL all_gather over xGMI)
+        # rank's tuples (count all_gather + ONE padded all_gather of bytes, RCCL over xGMI), then
+        # rebuilds the feature planes of all of them from the stone words
+        if packed:
+            keys = ("stones", "last", "ply", "z", "game_id", "pi")
+            if chunks:
+                mine = {key: torch.cat([d[key] for d in chunks]) for key in keys}
+            else:
+                mine = {"stones": torch.empty((0, 2, 4), dtype=torch.int64, device=dev), "last": torch.empty(0, dtype=torch.int32, device=dev),
+                        "ply": torch.empty(0, dtype=torch.int32, device=dev), "z": torch.empty(0, device=dev),
+                        "game_id": torch.empty(0, dtype=torch.int64, device=dev), "pi": torch.empty((0, n * n), dtype=torch.float64, device=dev)}
+            allr = azdist.gather_packed(mine, n * n)
+            total = int(allr["z"].shape[0])
+            if total:
+                states = eng.unpack_states(allr["stones"], allr["last"], allr["ply"])
+                assert states.shape == (total, 4, n, n)
+            return total
         if chunks:
             mine = {key: torch.cat([d[key] for d in chunks]) for key in ("states", "pi", "z", "game_id", "ply")}
         else:
