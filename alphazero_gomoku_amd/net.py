@@ -8,7 +8,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import _lib
+from . import _lib, model_files
 from .engine import SelfPlayEngine
 
 PARAM_ORDER = ["conv1.weight", "conv1.bias", "conv2.weight", "conv2.bias", "conv3.weight", "conv3.bias",
@@ -117,12 +117,24 @@ class PolicyValueNet(object):
 
     def load_model(self, model_file, layout=None):
         """A PyTorch state_dict file (what save_model and the reference's PyTorch net write,
-        policy_value_net_pytorch.py:150-157), or an .npz archive of the 16 parameter arrays
+        policy_value_net_pytorch.py:150-157), an .npz archive of the 16 parameter arrays
         (arr_0..arr_15) in the PyTorch layout or, with layout='theano' (or a 'layout' entry in
-        the archive saying so), in the layout of the reference's Theano/numpy model files.
-        Files are read with loaders that execute nothing from them (weights_only=True,
-        allow_pickle=False); a pickled Theano model has to be converted where it is trusted:
-        np.savez(path, *pickle.load(open(model, 'rb'), encoding='bytes'), layout='theano')."""
+        the archive saying so), in the layout of the reference's Theano/numpy model files, or such
+        a model file itself: the pickled list of 16 arrays that policy_value_net.py:113-121 writes
+        and policy_value_net_numpy.py:87-90 reads (Theano layout).
+        Files are read with loaders that execute nothing from them: weights_only=True,
+        allow_pickle=False, and for the pickled lists model_files.read_pickled_arrays, which only
+        disassembles the file and refuses anything but plain float arrays."""
+        if not str(model_file).endswith(".npz") and model_files.looks_like_pickle(model_file):
+            try:
+                params = model_files.read_pickled_arrays(model_file)
+            except ValueError:
+                params = None                      # e.g. a state_dict in torch's legacy pickle format: below
+            if params is not None:
+                if len(params) != 16:
+                    raise ValueError("%s holds %d arrays, a model of this net has 16" % (model_file, len(params)))
+                self.load_numpy_params(theano_to_torch_layout(params) if layout in (None, "theano") else params)
+                return
         if str(model_file).endswith(".npz"):
             with np.load(model_file, allow_pickle=False) as z:
                 if layout is None and "layout" in z.files:

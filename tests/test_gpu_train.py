@@ -82,6 +82,23 @@ def test_bundled_trained_nets_through_the_engine(az, cnn_mode):
         eng.close()
 
 
+def test_policy_value_net_loads_the_references_pickled_model_format(az, tmp_path):
+    """PolicyValueNet(model_file=...) on a file in the format of the reference's bundled
+    best_policy_*.model (a protocol-2 pickle of the 16 Theano-layout arrays,
+    policy_value_net.py:113-121), written here from the fixture's arrays: read without unpickling
+    (model_files.read_pickled_arrays) and evaluated by the HIP CNN within 1e-5 of the outputs the
+    reference's numpy net gave for the same weights."""
+    import pickle
+    d = helpers.load_golden("g10_trained.npz")
+    for n in (6, 8):
+        f = tmp_path / ("best_policy_%d.model" % n)
+        with open(f, "wb") as fh:
+            pickle.dump([np.asarray(d["params_%d_%d" % (n, i)]) for i in range(16)], fh, protocol=2)
+        net = az.PolicyValueNet(n, n, model_file=str(f))
+        probs, vals = net.policy_value(d["states_%d" % n].astype(np.float32))
+        assert np.abs(probs - d["probs_%d" % n]).max() < 1e-5 and np.abs(vals[:, 0] - d["values_%d" % n]).max() < 1e-5
+
+
 def test_activation_range_guard(az):
     """Split-f16 operands overflow above 65504: an activation that large must raise (sticky, named),
     never return numbers; the float32 variant evaluates the same net."""

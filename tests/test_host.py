@@ -329,3 +329,55 @@ def test_packed_gather_two_ranks_gloo():
     for key in res[0][3]:
         want = np.concatenate([res[0][3][key], res[1][3][key]])
         assert np.array_equal(res[0][2][key], want) and np.array_equal(res[1][2][key], want), key
+
+
+def test_pickled_model_files_are_read_without_unpickling(tmp_path):
+    """model_files.read_pickled_arrays on files this test writes in the format of the reference's
+    Theano / numpy nets (policy_value_net.py:113-121: pickle.dump(list of arrays, protocol=2)) and in
+    Python 3's default protocol: the arrays come back bit for bit; a file whose pickle program would
+    call something, hold other data or lie about its sizes is refused and nothing from it runs."""
+    import pickle
+    from alphazero_gomoku_amd import model_files
+    params = helpers.torch_to_theano_layout(helpers.make_params(6, seed=5))
+    for proto in (0, 1, 2, 3, 4):
+        f = tmp_path / ("m%d.model" % proto)
+        with open(f, "wb") as fh:
+            pickle.dump([np.asarray(p) for p in params], fh, protocol=proto)
+        assert model_files.looks_like_pickle(f) or proto < 2
+        got = model_files.read_pickled_arrays(f)
+        assert len(got) == 16
+        for a, b in zip(got, params):
+            assert a.dtype == np.float32 and a.shape == np.asarray(b).shape and np.array_equal(a, b)
+    # float64 arrays (what a numpy net trained in double would hold) come back as float32
+    f = tmp_path / "d.model"
+    with open(f, "wb") as fh:
+        pickle.dump([np.arange(6, dtype=np.float64).reshape(2, 3) / 3], fh, protocol=2)
+    assert np.array_equal(model_files.read_pickled_arrays(f)[0], (np.arange(6, dtype=np.float64).reshape(2, 3) / 3).astype(np.float32))
+    # a pickle that would run a command when unpickled: refused, and the command has not run
+    marker = tmp_path / "ran"
+
+    class Evil(object):
+        def __reduce__(self):
+            return (os.system, ("touch %s" % marker,))
+    for payload in ([Evil()], Evil(), [np.zeros(3, dtype=np.float32), Evil()]):
+        f = tmp_path / "evil.model"
+        with open(f, "wb") as fh:
+            pickle.dump(payload, fh, protocol=2)
+        with pytest.raises(ValueError):
+            model_files.read_pickled_arrays(f)
+    assert not marker.exists()
+    # other refusals: not a list, integer arrays, object arrays, a dict, truncated file, no pickle at all
+    for i, payload in enumerate((np.zeros(3, dtype=np.float32), [np.zeros(3, dtype=np.int32)], [np.array([None, 1], dtype=object)],
+                                 {"a": np.zeros(2, dtype=np.float32)}, [1.5, 2.5], [[np.zeros(2, dtype=np.float32)]])):
+        f = tmp_path / ("bad%d.model" % i)
+        with open(f, "wb") as fh:
+            pickle.dump(payload, fh, protocol=2)
+        with pytest.raises(ValueError):
+            model_files.read_pickled_arrays(f)
+    good = tmp_path / "m2.model"
+    blob = open(good, "rb").read()
+    (tmp_path / "cut.model").write_bytes(blob[: len(blob) // 2])
+    (tmp_path / "text.model").write_bytes(b"not a pickle at all")
+    for name in ("cut.model", "text.model"):
+        with pytest.raises(ValueError):
+            model_files.read_pickled_arrays(tmp_path / name)
