@@ -19,6 +19,7 @@
 // footprint at ~72 KB so that two workgroups share a CU and one's tree / FC / softmax
 // phases overlap the other's MFMA phases.
 #pragma once
+#include <type_traits>
 #include "azg_cnn.hpp"
 
 namespace azg {
@@ -364,6 +365,227 @@ __device__ inline void conv3x3_f16(const half8 *wp, WRing<RING, CW> &ring, const
         if (sub * PT + i < G::NT)                              // wave-uniform: epilogues may use MFMA
 #pragma unroll
             for (int c = 0; c < CW; c++) epi(c, cg * CW + c, sub * PT + i, acc[c][i], prow[i], ctx);
+}
+
+// ---------------------------------------------------------------- conv3 in Winograd form
+// F(2x2, 3x3): a 2x2 block of outputs is Y = A^T [ (G g G^T) .* (B^T d B) ] A summed over the input
+// channels, d the 4x4 input patch around the block.  Per element xi = (a, b) of the 4x4 transform
+// domain this is ONE GEMM over the input channels, M_xi[co][col] = sum_ci U_xi[co][ci] V_xi[ci][col],
+// col = (leaf, block): 16 GEMMs of K = 64 instead of one of K = 576, 2.25 times fewer multiplies.
+//   U = G g G^T comes packed from the host (split halves, MFMA A-operand order, k-step = xi*4 + cg).
+//   V_xi = (B^T d B)[a][b] is +-d[r0][c0] +-d[r0][c1] +-d[r1][c0] +-d[r1][c1] (every row of B^T has
+//   two entries +-1): the 256 threads build it from the A2 images into a 32-column image of the
+//   same row format (hi / lo), double buffered, while the MFMAs of the previous xi run.
+//   Y[i][j] += +-M_xi (A^T has entries 0, +-1) on the VALU, into four accumulator tiles per wave.
+// For the geometries with two leaves per workgroup (boards up to 8x8): 2 * ceil(N/2)^2 <= 32 columns.
+// OFF by default (-DAZG_WINO3=1 builds it in).  Measured at 8x8 / 400 playouts / 1024 games: the same
+// outputs to 1e-8; 192 instead of 432 MFMAs per wave and layer and the XCDs clock 13 % higher (2.23
+// instead of 1.97 GHz at 1 260 W), but the step takes 16 % more cycles -- 11.75 against 11.43 ms per
+// launch: the two transforms cost 1 800 VALU instructions per wave, the LDS moves the same 1.15 MB
+// per layer in half the time it had (V written and read back on top of the patch reads), and sixteen
+// barriers tie the four waves together.  Without the input transform's arithmetic (timing only) it
+// runs in 10.4 ms, which bounds what a cheaper transform could reach.
+#ifndef AZG_WINO3
+#define AZG_WINO3 0
+#endif
+#ifndef AZG_WINO_RING
+#define AZG_WINO_RING 3       // k-steps of U in flight per wave
+#endif
+#ifndef AZG_WINO_PRIO
+#define AZG_WINO_PRIO 2
+#endif
+
+// compile-time loop: f(std::integral_constant<int, I>) for I = B .. E-1 (every index a constant expression)
+template <int B, int E, class F>
+__device__ __forceinline__ void static_for(F &&f)
+{
+    if constexpr (B < E) {
+        f(std::integral_constant<int, B>{});
+        static_for<B + 1, E>(f);
+    }
+}
+
+// rows of B^T (input transform): the two patch indices with a non-zero entry and their signs
+__device__ __forceinline__ constexpr int wino_bt_idx(int a, int k) { return a == 0 ? (k ? 2 : 0) : a == 3 ? (k ? 3 : 1) : (k ? 2 : 1); }
+__device__ __forceinline__ constexpr bool wino_bt_neg(int a, int k) { return a == 0 ? k == 1 : a == 1 ? false : a == 2 ? k == 0 : k == 1; }
+// column a of A^T (output transform): sign of its entry in row i, 0 if none
+__device__ __forceinline__ constexpr int wino_at(int i, int a) { return i == 0 ? (a < 3 ? 1 : 0) : (a == 0 ? 0 : a == 1 ? 1 : -1); }
+
+// wp: U image of this layer; xh / xl: the A2 images; vbuf: 2 * 2 * 32 * RS_A2 bytes of LDS that are
+// free until the epilogue (the epilogue may overwrite them: the loop ends with a barrier).
+// epi(0, cot, -1, acc, p, ctx) is called four times (the 2x2 output positions of every block), p the
+// position of this lane's column or -1.
+template <class G, int RING, class Prep, class Epi>
+__device__ inline void conv3_wino_f16(const half8 *wp, const char *xh, const char *xl, char *vbuf, int wave, int lane,
+                                      int tid, Prep prep, Epi epi, Prof *prof)
+{
+    constexpr int N = G::N, TW = (N + 1) / 2, TPL = TW * TW, NCOL = G::T * TPL;
+    static_assert(NCOL <= 32, "one 32-column tile holds every 2x2 block of the workgroup's leaves");
+    constexpr int RS = G::RS_A2, VB = NCOL * RS, KS = 64;     // columns past NCOL are never written; what lanes read there is discarded
+    static_assert(4 * VB <= G::A2H_OFF, "the V buffers must fit in front of the A2 images");
+    const int half = lane >> 5, j = lane & 31;
+    // ---- builder role of this thread: column bc, channels 8*cblk .. 8*cblk+7
+    const int bc = tid & 31, cblk = tid >> 5;
+    int poff[16];                                   // byte offset of patch element (r, c) of the column's block, or the zero row
+    {
+        const bool live = bc < NCOL;
+        const int leaf = bc / TPL, t = bc - leaf * TPL, ty = t / TW, tx = t - ty * TW;
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const int y = 2 * ty - 1 + r, x = 2 * tx - 1 + c;
+                const bool ok = live && y >= 0 && y < N && x >= 0 && x < N;
+                poff[4 * r + c] = (ok ? leaf * G::S + y * N + x : G::NP) * RS + cblk * 16;
+            }
+    }
+    const int voff = bc * RS + cblk * 16;           // where this thread's 8 channels of V go
+    // +-1 as a register the compiler cannot see through: fma(half, one, acc) then selects
+    // v_fma_mix_f32 (the half read straight from its packed pair, widened exactly), where a literal
+    // +-1 would be folded into a conversion plus an addition -- two instructions per term
+    float one = 1.0f;
+    asm volatile("" : "+v"(one));
+
+    // ---- GEMM role: this wave owns channel tile `wave`, all 32 columns
+    const gptr<half8> wrow = as_global(wp + (size_t)wave * KS * 128 + lane * kWLane);
+    half8 ah[RING], al[RING];
+#pragma unroll
+    for (int d = 0; d < RING; d++) { ah[d] = wrow[(size_t)d * 128]; al[d] = wrow[(size_t)d * 128 + kWLo]; }
+    const f32x16 zacc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    f32x16 y[2][2] = {{zacc, zacc}, {zacc, zacc}};
+    const int boff = j * RS + half * 16;
+
+    // One element xi of the transform domain is twelve MFMAs (four k-steps, three products) in a
+    // dependent chain; everything else of the step is cut into twelve slices, one behind each MFMA
+    // (scheduling fences between the slices: left to itself the compiler issues the whole input
+    // transform first and the MFMAs last, and the matrix pipe idles through the transform):
+    //   * the input transform of element xi + 1: per patch element q its high halves (8 mixed
+    //     FMAs), then its low halves; the split and the two stores; LDS reads two slices ahead;
+    //   * the output transform of element xi - 1 (its M is complete; 16 additions per affected
+    //     Y tile): the first slices and the last;
+    //   * the activation reads of the next k-step and the weight loads RING k-steps ahead.
+    f32x16 mprev = zacc;
+    half8 dh[4], dl[4], bh[4], bl[4];
+    float acc[8];
+    auto d_off = [&](auto xi_c, int q) {
+        constexpr int xi = decltype(xi_c)::value;
+        return poff[4 * wino_bt_idx(xi >> 2, q >> 1) + wino_bt_idx(xi & 3, q & 1)];
+    };
+    auto yadd = [&](auto xi_c, int part) {           // output transform of element xi from mprev; part 0: tiles (0,*), 1: (1,*)
+        constexpr int xi = decltype(xi_c)::value;
+        constexpr int a = xi >> 2, b = xi & 3;
+#pragma unroll
+        for (int jj = 0; jj < 2; jj++) {
+            const int sg = wino_at(part, a) * wino_at(jj, b);
+            if (sg > 0) {
+#pragma unroll
+                for (int e = 0; e < 16; e++) y[part][jj][e] += mprev[e];
+            } else if (sg < 0) {
+#pragma unroll
+                for (int e = 0; e < 16; e++) y[part][jj][e] -= mprev[e];
+            }
+        }
+    };
+    auto mix = [&](auto xi_c, int q, bool low) {      // one slice of the input transform of element xi
+        constexpr int xi = decltype(xi_c)::value;
+        const bool neg = wino_bt_neg(xi >> 2, q >> 1) != wino_bt_neg(xi & 3, q & 1);
+        const float sg = neg ? -one : one;
+        if (!low) {
+#pragma unroll
+            for (int e = 0; e < 8; e++) acc[e] = __builtin_fmaf((float)dh[q][e], sg, q == 0 ? 0.0f : acc[e]);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; e++) acc[e] = __builtin_fmaf((float)dl[q][e], sg, acc[e]);
+        }
+    };
+    auto vstore = [&](char *vb) {
+        u32x4 vh, vl;
+#pragma unroll
+        for (int e2 = 0; e2 < 4; e2++) {
+            unsigned hh, ll;
+            split2_f16(acc[2 * e2], acc[2 * e2 + 1], hh, ll);
+            vh[e2] = hh;
+            vl[e2] = ll;
+        }
+        if (NCOL == 32 || bc < NCOL) {
+            *reinterpret_cast<u32x4 *>(vb + voff) = vh;
+            *reinterpret_cast<u32x4 *>(vb + VB + voff) = vl;
+        }
+    };
+    // element 0's transform, nothing to overlap it with
+    {
+        const std::integral_constant<int, 0> x0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            dh[q] = *reinterpret_cast<const half8 *>(xh + d_off(x0, q));
+            dl[q] = *reinterpret_cast<const half8 *>(xl + d_off(x0, q));
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) { mix(x0, q, false); mix(x0, q, true); }
+        vstore(vbuf);
+    }
+    __syncthreads();
+    __builtin_amdgcn_s_setprio(AZG_WINO_PRIO);
+    static_for<0, 16>([&](auto xi_c) {
+        constexpr int xi = decltype(xi_c)::value;
+        constexpr bool more = xi + 1 < 16;
+        const std::integral_constant<int, more ? xi + 1 : xi> xn;       // the element whose transform is built here
+        const std::integral_constant<int, xi ? xi - 1 : 0> xp;          // the element whose M is folded into Y here
+        const char *vc = vbuf + (xi & 1) * 2 * VB;
+        char *vn = vbuf + ((xi + 1) & 1) * 2 * VB;
+        f32x16 m = zacc;
+        auto bload = [&](int cg) {
+            bh[cg] = *reinterpret_cast<const half8 *>(vc + boff + cg * 32);
+            bl[cg] = *reinterpret_cast<const half8 *>(vc + VB + boff + cg * 32);
+        };
+        auto dload = [&](int q) {
+            if (more) {
+                dh[q] = *reinterpret_cast<const half8 *>(xh + d_off(xn, q));
+                dl[q] = *reinterpret_cast<const half8 *>(xl + d_off(xn, q));
+            }
+        };
+        bload(0);
+        dload(0);
+        bload(1);
+#pragma unroll
+        for (int s = 0; s < 12; s++) {
+            const int cg = s / 3, pr = s % 3, ks = xi * 4 + cg, ca = ks % RING;
+            if (pr == 0) m = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ca], bh[cg], m, 0, 0, 0);
+            if (pr == 1) m = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[ca], bh[cg], m, 0, 0, 0);
+            if (pr == 2) {
+                m = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ca], bl[cg], m, 0, 0, 0);
+                if (ks + RING < KS) { ah[ca] = wrow[(size_t)(ks + RING) * 128]; al[ca] = wrow[(size_t)(ks + RING) * 128 + kWLo]; }
+            }
+            // the slice behind MFMA s
+            if (s == 0) { if (xi) yadd(xp, 0); dload(1); }
+            if (s == 1) { if (xi) yadd(xp, 1); bload(2); }
+            if (s >= 2 && s < 10 && more) mix(xn, (s - 2) >> 1, ((s - 2) & 1) != 0);
+            if (s == 3) dload(2);
+            if (s == 4) bload(3);
+            if (s == 5) dload(3);
+            if (s == 10 && more) vstore(vn);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        mprev = m;
+        __syncthreads();                 // V[xi + 1] is complete, V[xi] may be overwritten (after the last xi: by the epilogue)
+    });
+    yadd(std::integral_constant<int, 15>{}, 0);
+    yadd(std::integral_constant<int, 15>{}, 1);
+    __builtin_amdgcn_s_setprio(0);
+    if (prof) prof->mark(11);
+    const auto ctx = prep();
+    {
+        const bool live = j < NCOL;
+        const int leaf = j / TPL, t = j - leaf * TPL, ty = t / TW, tx = t - ty * TW;
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int jj = 0; jj < 2; jj++) {
+                const int yy = 2 * ty + i, xx = 2 * tx + jj;
+                const int p = (live && yy < N && xx < N) ? leaf * G::S + yy * N + xx : -1;
+                epi(0, wave, -1, y[i][jj], p, ctx);
+            }
+    }
 }
 
 // Wave-wide float reductions on the DPP network (lane^1, lane^2, mirror within 8, mirror within
@@ -843,6 +1065,7 @@ __device__ inline void cnn16_forward(const NetWeights &nw_in, float *lds, InputF
 #endif
     constexpr int R2 = ConvWaves<G>::CW == 2 ? 4 : AZG_R2, R3 = AZG_R3;                    // k-steps of weights in flight per layer (conv1: all three)
     constexpr int CW2 = ConvWaves<G>::CW, CW3 = ConvWaves<G>::CW;
+    constexpr bool kWino3 = AZG_WINO3 && G::T == 2 && CW3 == 1;      // conv3 in Winograd form (two-leaf geometries)
     const half8 *w1 = reinterpret_cast<const half8 *>(nw.w16[0]);
     const half8 *w2 = reinterpret_cast<const half8 *>(nw.w16[1]);
     const half8 *w3 = reinterpret_cast<const half8 *>(nw.w16[2]);
@@ -918,7 +1141,7 @@ __device__ inline void cnn16_forward(const NetWeights &nw_in, float *lds, InputF
     if (tid == 0) gate.acquire();
     __syncthreads();
     prof.mark(3);
-    conv_preload<G, 64, 128, R3, CW3>(w3, wave, lane, ring3);
+    if constexpr (!kWino3) conv_preload<G, 64, 128, R3, CW3>(w3, wave, lane, ring3);
     conv3x3_f16<G, 32, 64, G::RS_A1, true, G::BPF, R2, CW2>(w2, ring2, ldb + G::A1H_OFF, ldb + G::A1L_OFF, wave, lane,
                                                load_bias(lbias + 32, (wave % ConvSplit<G, 64, CW2>::WC) * CW2, CW2),
                                                store_split(ldb + G::A2H_OFF, ldb + G::A2L_OFF, G::RS_A2),
@@ -941,8 +1164,7 @@ __device__ inline void cnn16_forward(const NetWeights &nw_in, float *lds, InputF
         struct Head16 { f32x4 b[CW3][4]; half8 w[CW3][2]; };
         float *hp = lds + G::HP_OFF + cg3 * 8 * G::NTP;
         f32x16 hd;                                         // head sums of the position tile in work, over the wave's channel tiles
-        conv3x3_f16<G, 64, 128, G::RS_A2, true, G::BPF, R3, CW3>(w3, ring3, ldb + G::A2H_OFF, ldb + G::A2L_OFF, wave, lane,
-            [=]() {
+        auto head_prep = [=]() {
                 Head16 c;
 #pragma unroll
                 for (int t = 0; t < CW3; t++) {
@@ -955,8 +1177,8 @@ __device__ inline void cnn16_forward(const NetWeights &nw_in, float *lds, InputF
                     for (int s2 = 0; s2 < 2; s2++) c.w[t][s2] = *reinterpret_cast<const half8 *>(whp + s2 * 512);
                 }
                 return c;
-            },
-            [=, &hd](int ci, int, int tile, const f32x16 &acc, int p, const Head16 &c) {
+            };
+        auto head_epi = [=, &hd](int ci, int, int tile, const f32x16 &acc, int p, const Head16 &c) {
                 const f32x16 zacc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
                 if (ci == 0) hd = zacc;
 #pragma unroll
@@ -980,11 +1202,20 @@ __device__ inline void cnn16_forward(const NetWeights &nw_in, float *lds, InputF
                 // rows 0-3 of the head tile sit in registers 0-3 of lanes 0-31, rows 4-7 in
                 // registers 0-3 of lanes 32-63 (rows 6, 7 are zero: their weights are); the
                 // low-half rows 8-15 sit in registers 4-7 of the same lanes
-                if (G::NP != G::NTP && p < 0) return;       // padding lane of the last tile
-                float *dst = hp + (4 * half) * G::NTP + tile * 32 + j;
+                if ((G::NP != G::NTP || kWino3) && p < 0) return;       // padding lane of the last tile / no such position
+                // (the direct path addresses by tile and lane, not by p, although the two are equal there:
+                // with p the compiler pairs the stores of tiles t and t + 2 into ds_write2st64_b32 and the
+                // first leaf's sums came out wrong on the GPU -- measured, not understood)
+                float *dst = hp + (4 * half) * G::NTP + (kWino3 ? p : tile * 32 + j);
 #pragma unroll
                 for (int c4 = 0; c4 < 4; c4++) dst[c4 * G::NTP] = hd[c4] + hd[4 + c4];
-            }, &prof);
+            };
+        if constexpr (kWino3)
+            conv3_wino_f16<G, AZG_WINO_RING>(reinterpret_cast<const half8 *>(nw.w16w3), ldb + G::A2H_OFF, ldb + G::A2L_OFF, ldb, wave, lane, tid,
+                                 head_prep, head_epi, &prof);
+        else
+            conv3x3_f16<G, 64, 128, G::RS_A2, true, G::BPF, R3, CW3>(w3, ring3, ldb + G::A2H_OFF, ldb + G::A2L_OFF, wave, lane,
+                                                                   head_prep, head_epi, &prof);
     }
     prof.mark(5);
     __syncthreads();

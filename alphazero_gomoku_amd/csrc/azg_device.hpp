@@ -39,6 +39,7 @@ __host__ __device__ inline int meta_k(unsigned m) { return (int)(m >> 16); }
 struct NetWeights {
     const float *wconv[3];   // packed conv1..conv3 (float32 path)
     const void *w16[3];      // packed conv1..conv3 as split halves (azg_cnn16.hpp)
+    const void *w16w3;       // conv3 in Winograd form, G g G^T as split halves (azg_cnn16.hpp, conv3_wino_f16)
     const void *wfc16[2];    // act_fc1 / val_fc1 as split halves in MFMA A-operand order (azg_cnn16.hpp)
     const void *whead16;     // the two 1x1 head convolutions as split halves (azg_cnn16.hpp), 4 KB
     const float *bconv[3];   // biases [32],[64],[128]
@@ -78,6 +79,7 @@ __device__ inline NetWeights opaque_weights(const NetWeights &w)
     for (int i = 0; i < 3; i++) { o.wconv[i] = opaque(w.wconv[i]); o.w16[i] = opaque((const char *)w.w16[i]); o.bconv[i] = opaque(w.bconv[i]); }
     for (int i = 0; i < 2; i++) o.wfc16[i] = opaque((const char *)w.wfc16[i]);
     o.whead16 = opaque((const char *)w.whead16);
+    o.w16w3 = opaque((const char *)w.w16w3);
     o.whead = opaque(w.whead); o.bhead = opaque(w.bhead); o.wpfc = opaque(w.wpfc); o.bpfc = opaque(w.bpfc);
     o.wvfc1 = opaque(w.wvfc1); o.bvfc1 = opaque(w.bvfc1); o.wvfc2 = opaque(w.wvfc2); o.bvfc2 = opaque(w.bvfc2);
     o.wpfc_k = opaque(w.wpfc_k); o.wvfc1_k = opaque(w.wvfc1_k);

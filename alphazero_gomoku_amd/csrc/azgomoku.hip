@@ -587,6 +587,38 @@ static void pack_conv16(const float *w, int cin, int cinp, int cout, _Float16 *o
             }
 }
 
+// conv3 in Winograd F(2x2, 3x3) form for azg_cnn16.hpp's conv3_wino_f16: U = G g G^T of every
+// (co, ci) kernel, G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]], computed in double; per (cotile,
+// kstep = xi*CG + cg) with xi = 4a + b the element of the 4x4 transform domain, and lane, 8 high halves
+// then 8 low halves of U[a][b](co = cotile*32 + (lane&31), ci = cg*16 + 8*(lane>>5) + j) * 2^8.
+// Returns the largest |U| (the caller checks the half-precision range).
+static double pack_wino16(const float *w, int cin, int cout, _Float16 *out)
+{
+    static const double Gm[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
+    const int CG = cin / 16, KS = 16 * CG;
+    double umax = 0.0;
+    for (int cot = 0; cot < cout / 32; cot++)
+        for (int ks = 0; ks < KS; ks++)
+            for (int lane = 0; lane < 64; lane++) {
+                const int xi = ks / CG, cg = ks % CG, a = xi >> 2, b = xi & 3;
+                const int co = cot * 32 + (lane & 31);
+                _Float16 *dst = out + ((size_t)cot * KS + ks) * 1024;
+                for (int j = 0; j < 8; j++) {
+                    const int ci = cg * 16 + 8 * (lane >> 5) + j;
+                    const float *g = w + ((size_t)co * cin + ci) * 9;
+                    double u = 0.0;
+                    for (int r = 0; r < 3; r++)
+                        for (int c = 0; c < 3; c++) u += Gm[a][r] * (double)g[3 * r + c] * Gm[b][c];
+                    umax = std::max(umax, std::fabs(u));
+                    const float v = (float)u * kWScale;
+                    const _Float16 hi = (_Float16)v;
+                    dst[wsplit_off(lane, j)] = hi;
+                    dst[wsplit_off(lane, 8 + j)] = (_Float16)(v - (float)hi);
+                }
+            }
+    return umax;
+}
+
 // Split-f16 image of conv1 for azg_cnn16.hpp's conv1_packed_f16: k = tap*4 + plane in three k-steps
 // of 16; per k-step and lane 8 high then 8 low halves of W[co = lane&31][plane = j%4][tap = 4*ks +
 // 2*(lane>>5) + j/4] * 2^8, zero for tap >= 9.
@@ -699,6 +731,8 @@ extern "C" int azg_set_weights(azg_handle *h, const float *const ptrs[16], int l
     // row-per-input images of the two wide FC layers (sparse-input FC of the one-leaf kernels)
     const size_t offpk = total, offvk = offpk + (size_t)4 * S * 256;
     total = offvk + (size_t)2 * S * 64;
+    const size_t offw3 = total;                              // conv3 in Winograd form: 4 cotiles * 64 k-steps * 1024 halves
+    if (AZG_WINO3) total += (size_t)4 * 64 * 512;
     if (h->cfg.cnn_mode == AZG_CNN_F16X3) {
         // halves hold w * 2^8: larger weights would overflow to infinity
         for (int i : {0, 2, 4, 6, 8, 10, 12})
@@ -714,6 +748,12 @@ extern "C" int azg_set_weights(azg_handle *h, const float *const ptrs[16], int l
     pack_conv1_16(t[0].data(), reinterpret_cast<_Float16 *>(&host[off16[0]]));
     pack_conv16(t[2].data(), 32, 32, 64, reinterpret_cast<_Float16 *>(&host[off16[1]]));
     pack_conv16(t[4].data(), 64, 64, 128, reinterpret_cast<_Float16 *>(&host[off16[2]]));
+    if (AZG_WINO3) {
+        const double umax = pack_wino16(t[4].data(), 64, 128, reinterpret_cast<_Float16 *>(&host[offw3]));
+        if (h->cfg.cnn_mode == AZG_CNN_F16X3 && h->cfg.board_n <= 8 && !(umax < 240.0))
+            return fail(h, AZG_EINVAL, "conv3 holds kernels whose Winograd transform reaches |u| >= 240: out of range for the "
+                        "split-f16 convolutions, create the engine with AZG_CNN_F32");
+    }
     pack_fc16(t[8].data(), S, 4 * S, otp, ksp, reinterpret_cast<_Float16 *>(&host[offfc[0]]));
     pack_fc16(t[12].data(), 64, 2 * S, 4, ksv, reinterpret_cast<_Float16 *>(&host[offfc[1]]));
     std::copy(t[1].begin(), t[1].end(), &host[off[3]]);
@@ -743,6 +783,7 @@ extern "C" int azg_set_weights(azg_handle *h, const float *const ptrs[16], int l
     const float *d = h->d_weights;
     nw.wconv[0] = d + off[0]; nw.wconv[1] = d + off[1]; nw.wconv[2] = d + off[2];
     nw.w16[0] = d + off16[0]; nw.w16[1] = d + off16[1]; nw.w16[2] = d + off16[2];
+    nw.w16w3 = AZG_WINO3 ? d + offw3 : nullptr;
     nw.wfc16[0] = d + offfc[0]; nw.wfc16[1] = d + offfc[1];
     nw.whead16 = d + offh16;
     nw.bconv[0] = d + off[3]; nw.bconv[1] = d + off[4]; nw.bconv[2] = d + off[5];
