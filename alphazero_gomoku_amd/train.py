@@ -74,6 +74,7 @@ class TrainPipeline:
         self._engine_version = -1
         self.episode_len = 0
         self.policy_updates = 0
+        self.loss_history = []                   # (loss, entropy) of every policy update, in the order they ran
         self._runner = None                      # continuous mode: the self-play run that never stops
         self._chunks, self._games_in_chunks = [], 0
         self._todo = []                          # continuous mode: policy updates still to issue
@@ -187,6 +188,7 @@ class TrainPipeline:
         self.explained_var_new = 1 - np.var(wz - nv) / var_z if var_z > 0 else float("nan")
         self.last_kl = kl
         self.policy_updates += 1
+        self.__dict__.setdefault("loss_history", []).append((loss, entropy))
         return loss, entropy
 
     def _agree(self, kl):
@@ -325,6 +327,21 @@ def main(argv=None):
     if world > 1:
         from . import dist as azdist
         azdist.broadcast_weights(tp.policy_value_net)
+    # One-time library initialisation stays outside the timer: the first optimiser step of a process
+    # makes MIOpen pick (and on a fresh machine compile) its convolution kernels, seconds that say
+    # nothing about the loop.  A scratch net of the same shape takes one step on zeros; the
+    # pipeline's own net, optimizer state and random streams are untouched.
+    from .net import PolicyValueNet
+    scratch = PolicyValueNet(args.board, args.board, device=local)
+    dev = torch.device("cuda", local)
+    nb = max(1, args.batch_size // world)
+    scratch.train_step(torch.zeros((nb, 4, args.board, args.board), device=dev), torch.full((nb, args.board * args.board), 1.0 / (args.board * args.board), device=dev),
+                       torch.zeros(nb, device=dev), 1e-3)
+    scratch.policy_value(torch.zeros((args.batch_size, 4, args.board, args.board), device=dev))
+    del scratch
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
     log = []
     t0 = time.perf_counter()
     tp.run(on_batch=lambda i, n, loss, ent: log.append((i, n, loss, ent)))
@@ -333,13 +350,14 @@ def main(argv=None):
     if rank == 0:
         if args.save:
             tp.policy_value_net.save_model(args.save)
-        losses = [l for _, _, l, _ in log if l is not None]
+        losses = [l for l, _ in tp.loss_history]
         print(json.dumps({"games": tp.games_played, "ranks": world, "seconds": dt, "games_per_s_incl_training": tp.games_played / dt,
                           "samples": int(sum(n for _, n, _, _ in log)), "policy_updates": tp.policy_updates,
                           "updates_per_batch": upb, "play_batch": args.play_batch, "continuous": bool(args.continuous),
                           "slots_per_gpu": tp.engine.B,
                           "first_loss": losses[0] if losses else None, "last_loss": losses[-1] if losses else None,
-                          "lr_multiplier": tp.lr_multiplier, "best_win_ratio": tp.best_win_ratio}))
+                          "lr_multiplier": tp.lr_multiplier, "best_win_ratio": tp.best_win_ratio,
+                          "timer": "starts after one optimiser step on a scratch net (library initialisation), ends after the last update"}))
     if world > 1:
         dist.destroy_process_group()
 
