@@ -62,8 +62,15 @@ __device__ inline void split2_f16(float v0, float v1, unsigned &h, unsigned &l)
 #ifndef AZG_CW2
 #define AZG_CW2 1
 #endif
+#ifndef AZG_CW1_3
+#define AZG_CW1_3 AZG_CW1     // conv3 of the one-leaf kernels (conv2 has two channel tiles in all, conv3 four)
+#endif
 template <class G>
-struct ConvWaves { static constexpr int CW = G::T == 1 ? AZG_CW1 : AZG_CW2, HPARTS = 4 / CW; };
+struct ConvWaves {
+    static constexpr int CW = G::T == 1 ? AZG_CW1 : AZG_CW2;            // conv2
+    static constexpr int CW3 = G::T == 1 ? AZG_CW1_3 : AZG_CW2;         // conv3
+    static constexpr int HPARTS = 4 / CW3;                               // channel groups of conv3 = partial sums per head output
+};
 // sum of a position's PARTS head partials (blocks of 8 rows, ntp floats per row, apart)
 template <int PARTS>
 __device__ inline float head_sum(const float *pp, int ntp)
@@ -1063,8 +1070,8 @@ __device__ inline void cnn16_forward(const NetWeights &nw_in, float *lds, InputF
 #ifndef AZG_R3
 #define AZG_R3 3
 #endif
-    constexpr int R2 = ConvWaves<G>::CW == 2 ? 4 : AZG_R2, R3 = AZG_R3;                    // k-steps of weights in flight per layer (conv1: all three)
-    constexpr int CW2 = ConvWaves<G>::CW, CW3 = ConvWaves<G>::CW;
+    constexpr int CW2 = ConvWaves<G>::CW, CW3 = ConvWaves<G>::CW3;
+    constexpr int R2 = CW2 == 2 ? 4 : AZG_R2, R3 = CW3 == 4 ? 1 : AZG_R3;                  // k-steps of weights in flight per layer (conv1: all three)
     constexpr bool kWino3 = AZG_WINO3 && G::T == 2 && CW3 == 1;      // conv3 in Winograd form (two-leaf geometries)
     const half8 *w1 = reinterpret_cast<const half8 *>(nw.w16[0]);
     const half8 *w2 = reinterpret_cast<const half8 *>(nw.w16[1]);

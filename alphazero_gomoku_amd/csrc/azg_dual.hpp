@@ -102,17 +102,18 @@ struct DualGeom : Cnn16Geom<N_, T_> {
     using GL = GameLdsT<N_ * N_ + 1>;
     static_assert(T_ == 1 && G::SPARSE_FC, "the dual kernel is built for the one-leaf geometries (boards above 8x8)");
     static constexpr int NG = 2 * T_;                                      // games per workgroup
-    // float offsets from here on.  The first set's input image is the one inside the CNN region
-    // (G::IN_OFF); the second set has its own, so that the tree waves can write the planes of a
-    // set's new leaf while the net waves still work on the other set.
-    static constexpr int IN1_OFF = (G::END + 3) & ~3;
-    static constexpr int IN_WORDS = (G::ROWS * G::RS_IN + 15) / 16 * 4;
-    static constexpr int GL_OFF = IN1_OFF + IN_WORDS;
+    // float offsets from here on.  The input image (G::IN_OFF, inside the CNN region) is written and
+    // read by the tree waves only, within one turn (planes, then conv1): one image serves both sets.
+    static constexpr int GL_OFF = (G::END + 3) & ~3;
     static constexpr int GL_WORDS = (int)(sizeof(GL) / 4);
     // per set: the head convolutions' sums [6][S] (scaled by 2^8, without bias; the net waves ADD
     // their partial sums here, the tree waves clear it), then probabilities [S] and the value
+    // (with one channel tile per wave conv3 has four channel groups: two such blocks, each fed by two
+    // of them, added in the order of head_sum<4>)
     static constexpr int TX_OFF = 0;
-    static constexpr int TX_WORDS = (6 * G::S + 7) & ~7;
+    static constexpr int HB = ConvWaves<G>::HPARTS == 4 ? 2 : 1;         // blocks of head sums
+    static constexpr int TXB = (6 * G::S + 7) & ~7;
+    static constexpr int TX_WORDS = HB * TXB;
     static constexpr int TLG_OFF = TX_OFF + TX_WORDS;
     static constexpr int TVAL_OFF = TLG_OFF + ((G::S + 7) & ~7);
     static constexpr int TL_WORDS = TVAL_OFF + 8;
@@ -128,7 +129,7 @@ struct DualGeom : Cnn16Geom<N_, T_> {
     static constexpr int TOTAL = CTL_OFF + (int)(sizeof(DualCtl) / 4);
     static_assert(TOTAL * 4 <= 160 * 1024, "the dual kernel's LDS does not fit on a CU");
     static_assert(GL_WORDS % 2 == 0 && GL_OFF % 2 == 0 && TL_WORDS % 4 == 0 && YW_OFF % 4 == 0, "alignment of the records and of the vector accesses");
-    __device__ static char *in_image(float *lds, int set) { return reinterpret_cast<char *>(lds + (set ? IN1_OFF : 0)) + (set ? 0 : G::IN_OFF); }
+    __device__ static char *in_image(float *lds) { return reinterpret_cast<char *>(lds) + G::IN_OFF; }
 };
 
 // ---------------------------------------------------------------- convolution layers
@@ -138,8 +139,17 @@ struct DualGeom : Cnn16Geom<N_, T_> {
 #ifndef AZG_DUAL_PRIO
 #define AZG_DUAL_PRIO 2      // issue priority of the net waves (the critical path; they share their SIMDs with the tree waves)
 #endif
+#ifndef AZG_DUAL_TREE_PRIO
+#define AZG_DUAL_TREE_PRIO 0 // issue priority of the tree waves
+#endif
 #ifndef AZG_DUAL_R3
 #define AZG_DUAL_R3 2
+#endif
+#ifndef AZG_DUAL_R3_CW4
+#define AZG_DUAL_R3_CW4 1    // conv3 weight ring depth when a wave streams all four channel tiles (8 registers per tile and k-step)
+#endif
+#ifndef AZG_DUAL_TAIL_SYNC
+#define AZG_DUAL_TAIL_SYNC 0 // 1: a barrier of the tree waves behind the softmax (measured: not needed, costs ~0.6 k cycles per evaluation)
 #endif
 #ifndef AZG_FC_NT
 #define AZG_FC_NT 0          // 1: the sparse FC reads its weight rows with the non-temporal hint
@@ -199,15 +209,12 @@ struct StoreSplit {
 // conv1 of one leaf, run by the TREE waves (wave4 = 0..3) from the set's input image into the one
 // conv1 output image; the caller has waited until the net waves are done with that image.
 template <class D>
-__device__ inline void dual_conv1(const NetWeights &nw_in, float *lds, const char *xin, int wave4, int lane)
+__device__ inline void dual_conv1(W1Ring &ring1, float *lds, const char *xin, int wave4, int lane)
 {
     using G = typename D::G;
-    const NetWeights nw = opaque_weights(nw_in);
     char *ldb = reinterpret_cast<char *>(lds);
     constexpr int CW = ConvWaves<G>::CW;
     const float *lbias = lds + G::BIAS_OFF / 4;
-    W1Ring ring1;
-    conv1_preload(reinterpret_cast<const half8 *>(nw.w16[0]), lane, ring1);
     const StoreSplit<G, CW> st1 = {ldb + G::A1H_OFF, ldb + G::A1L_OFF, G::RS_A1, lane >> 5};
     conv1_packed_f16<G>(ring1, xin, wave4, lane, LoadBias<CW>{lbias, 0, 1, lane >> 5},
                         [=](int, int tile, const f32x16 &acc, int p, const Bias16<CW> &c) { st1(0, 0, tile, acc, p, c); }, nullptr, 13);
@@ -250,14 +257,14 @@ __device__ inline bool dual_front(const NetWeights &nw_in, float *lds, float *tl
     __builtin_assume(wave >= 0 && wave < 4);
     const int half = lane >> 5, j = lane & 31;
     const float *lbias = lds + G::BIAS_OFF / 4;
-    constexpr int CW = ConvWaves<G>::CW;
-    static_assert(ConvWaves<G>::HPARTS == 2, "two addends per head sum: the order of the atomic additions must not matter");
-    constexpr int R2 = 3, R3 = AZG_DUAL_R3;
+    constexpr int CW = ConvWaves<G>::CW, CW3 = ConvWaves<G>::CW3, HPARTS = ConvWaves<G>::HPARTS;
+    static_assert(HPARTS <= 2 * D::HB, "at most two addends per head sum: the order of the atomic additions must not matter");
+    constexpr int R2 = 3, R3 = CW3 == 4 ? AZG_DUAL_R3_CW4 : AZG_DUAL_R3;
     constexpr int BPF3 = AZG_DUAL_BPF3;
     const half8 *w2 = reinterpret_cast<const half8 *>(nw.w16[1]);
     const half8 *w3 = reinterpret_cast<const half8 *>(nw.w16[2]);
-    WRing<R3, CW> ring3;
-    conv_preload<G, 64, 128, R3, CW>(w3, wave, lane, ring3);
+    WRing<R3, CW3> ring3;
+    conv_preload<G, 64, 128, R3, CW3>(w3, wave, lane, ring3);
     conv3x3_f16<G, 32, 64, G::RS_A1, true, G::BPF, R2, CW, AZG_DUAL_PRIO != 0>(w2, rings.ring2, ldb + G::A1H_OFF, ldb + G::A1L_OFF, wave, lane,
         LoadBias<CW>{lbias + 32, (wave % ConvSplit<G, 64, CW>::WC) * CW, CW, half},
         StoreSplit<G, CW>{ldb + G::A2H_OFF, ldb + G::A2L_OFF, G::RS_A2, half}, &prof, 15);
@@ -267,17 +274,17 @@ __device__ inline bool dual_front(const NetWeights &nw_in, float *lds, float *tl
     if (tid == 0) lds_store(a1gen, a1count);           // every net wave is done with conv1's output
     prof.mark(4);
     {
-        using SP3 = ConvSplit<G, 128, CW>;
+        using SP3 = ConvSplit<G, 128, CW3>;
         const int cg3 = wave % SP3::WC;
-        struct Head16 { f32x4 b[CW][4]; half8 w[CW][2]; };
-        float *hx = tl + D::TX_OFF;
+        struct Head16 { f32x4 b[CW3][4]; half8 w[CW3][2]; };
+        float *hx = tl + D::TX_OFF + (cg3 >> 1) * D::TXB;       // channel groups 2g and 2g + 1 share a block
         f32x16 hd;
-        conv3x3_f16<G, 64, 128, G::RS_A2, true, BPF3, R3, CW, AZG_DUAL_PRIO != 0>(w3, ring3, ldb + G::A2H_OFF, ldb + G::A2L_OFF, wave, lane,
+        conv3x3_f16<G, 64, 128, G::RS_A2, true, BPF3, R3, CW3, AZG_DUAL_PRIO != 0>(w3, ring3, ldb + G::A2H_OFF, ldb + G::A2L_OFF, wave, lane,
             [=]() {
                 Head16 c;
 #pragma unroll
-                for (int t = 0; t < CW; t++) {
-                    const int cot = cg3 * CW + t;
+                for (int t = 0; t < CW3; t++) {
+                    const int cot = cg3 * CW3 + t;
                     const float *b3 = lbias + 96 + cot * 32;
                     const char *whp = ldb + G::WH_OFF + ((cot * 4 + half) * 8 + (j < 16 ? (j & 7) : 7)) * 32 + ((j >= 8 && j < 16) ? 16 : 0);
 #pragma unroll
@@ -307,13 +314,16 @@ __device__ inline bool dual_front(const NetWeights &nw_in, float *lds, float *tl
                     hd = __builtin_amdgcn_mfma_f32_32x32x16_f16(c.w[ci][s2], xh8, hd, 0, 0, 0);
                     hd = __builtin_amdgcn_mfma_f32_32x32x16_f16(c.w[ci][s2], xl8, hd, 0, 0, 0);
                 }
-                if (ci != CW - 1) return;
+                if (ci != CW3 - 1) return;
                 if (p < 0) return;                               // padding lane of the last tile
                 // head rows 0-3 sit in registers 0-3 of lanes 0-31, rows 4-7 in those of lanes 32-63
                 // (6 and 7 are not head channels); the low-half rows 8-15 in registers 4-7
 #pragma unroll
                 for (int c4 = 0; c4 < 4; c4++)
-                    if (4 * half + c4 < 6) atomicAdd(hx + (4 * half + c4) * G::S + p, hd[c4] + hd[4 + c4]);
+                    if (4 * half + c4 < 6) {
+                        if (HPARTS == 1) hx[(4 * half + c4) * G::S + p] = hd[c4] + hd[4 + c4];      // the wave holds all channels of its positions
+                        else atomicAdd(hx + (4 * half + c4) * G::S + p, hd[c4] + hd[4 + c4]);
+                    }
             }, &prof);
     }
     prof.mark(5);
@@ -346,8 +356,10 @@ __device__ inline bool dual_tail(const NetWeights &nw_in, float *lds, float *tl,
             float v = 0.0f;
             if (k < kmax) {
                 const int e = c0 * G::S + k;
-                v = relu_nan(__builtin_fmaf(hx[e], kWUnscale, bh[c0 + k / G::S]));
+                float sum = hx[e];
                 hx[e] = 0.0f;
+                if (D::HB == 2) { sum += hx[D::TXB + e]; hx[D::TXB + e] = 0.0f; }
+                v = relu_nan(__builtin_fmaf(sum, kWUnscale, bh[c0 + k / G::S]));
             }
             const bool nz = !(v <= 0.0f);
             const unsigned long long m = __ballot(nz);
@@ -452,7 +464,13 @@ __device__ inline bool dual_tail(const NetWeights &nw_in, float *lds, float *tl,
         if (lane == 0) tl[D::TVAL_OFF] = tanhf(v + lb[G::B_VFC2]);
     }
     prof.mark(9);
+#if defined(AZG_DUAL_DUMP) || AZG_DUAL_TAIL_SYNC
     return gs.sync();
+#else
+    // No barrier here: only wave 0 reads what it has just written (expand, backup), and the other
+    // waves meet it again at the barrier behind the next descent before they touch anything.
+    return true;
+#endif
 }
 
 // Board.current_state of the set's leaf (game.py:92-116) as the net's input image; tree waves.
@@ -508,8 +526,7 @@ __device__ __forceinline__ void search_dual_body(DevState st)
         // the head sums of both sets
         const half8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
         if (tid >= 256 && tid < 256 + G::RS_IN / 16) {
-            *reinterpret_cast<half8 *>(D::in_image(smem, 0) + G::NP * G::RS_IN + (tid - 256) * 16) = z8;
-            *reinterpret_cast<half8 *>(D::in_image(smem, 1) + G::NP * G::RS_IN + (tid - 256) * 16) = z8;
+            *reinterpret_cast<half8 *>(D::in_image(smem) + G::NP * G::RS_IN + (tid - 256) * 16) = z8;
         }
         if (tid >= 320 && tid < 320 + G::RS_A1 / 16) {
             *reinterpret_cast<half8 *>(ldb + G::A1H_OFF + G::NP * G::RS_A1 + (tid - 320) * 16) = z8;
@@ -556,6 +573,7 @@ __device__ __forceinline__ void search_dual_body(DevState st)
     }
 
     // ---- tree waves
+    if (AZG_DUAL_TREE_PRIO) __builtin_amdgcn_s_setprio(AZG_DUAL_TREE_PRIO);
     const int tid4 = tid - 256, wave4 = wave - 4;
     const bool tree_wave = wave4 < T;
     int it[2] = {0, 0};
@@ -619,12 +637,15 @@ __device__ __forceinline__ void search_dual_body(DevState st)
                 if (gl->live && gl->need_eval) {
                     // the leaf goes to the net waves: its input planes and conv1 first (all four tree
                     // waves), conv1 as soon as the net waves have read the previous conv1 output
-                    dual_fill_input<D>(D::in_image(smem, s), gl, tid4);
+                    // (conv1's weights are requested first: their L2 round trip passes behind the planes and the waits)
+                    W1Ring ring1;
+                    conv1_preload(reinterpret_cast<const half8 *>(opaque_weights(st.net).w16[0]), lane, ring1);
+                    dual_fill_input<D>(D::in_image(smem), gl, tid4);
                     if (!gs.sync()) { broke = true; break; }
                     prof.mark(7);
                     if (!wait_ge(&ctl->a1gen, n_conv1, &ctl->abort)) { broke = true; break; }
                     prof.mark(12);
-                    dual_conv1<D>(st.net, smem, D::in_image(smem, s), wave4, lane);
+                    dual_conv1<D>(ring1, smem, D::in_image(smem), wave4, lane);
                     n_conv1++;
                     if (!gs.sync()) { broke = true; break; }
                     prof.mark(13);

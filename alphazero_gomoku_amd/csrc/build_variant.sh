@@ -1,13 +1,14 @@
 #!/bin/sh
 # Experiment builds: sh build_variant.sh NAME [-D...]  ->  abx/libazg_NAME.so with the 8x8 split-f16
-# kernels only (select it with AZG_LIBRARY=abx/libazg_NAME.so).  Prints the register use of the search kernel.
+# kernels only (AZG_ONLY=15 in the environment: the 15x15 kernels only); select it with
+# AZG_LIBRARY=abx/libazg_NAME.so.  Prints the register use of the search kernel.
 set -e
 here="$(cd "$(dirname "$0")" && pwd)"
 name="$1"; shift
 mkdir -p "$here/../../abx"
 out="$here/../../abx/libazg_$name.so"
 log="$here/../../abx/build_$name.log"
-hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fno-slp-vectorize -fPIC -shared -std=c++17 -no-hip-rt -DAZG_ONLY8 \
+hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fno-slp-vectorize -fPIC -shared -std=c++17 -no-hip-rt -DAZG_ONLY${AZG_ONLY:-8} \
     -Rpass-analysis=kernel-resource-usage "$here/azgomoku.hip" -o "$out" -lpthread "$@" 2> "$log" || { tail -30 "$log" >&2; exit 1; }
-grep -A12 "Function Name: _ZN3azg21search_kernel_f16_8x8" "$log" | grep -E "VGPRs:|Spill|LDS Size|Occupancy" | sed "s/^.*remark: [^ ]* //" | tr '\n' ' '
+grep -A12 -E "Function Name: _ZN3azg(21search_kernel_f16_8x8|18search_dual_kernel)" "$log" | grep -E "VGPRs:|Spill|LDS Size|Occupancy" | sed "s/^.*remark: [^ ]* //" | tr '\n' ' '
 echo " -> $out"
