@@ -16,6 +16,12 @@ def shard_game_ids(rank, world, n_games_total):
     return rank, world, count
 
 
+def _comm_device(dev, group=None):
+    """Device the collectives' buffers live on: the tensors' own (RCCL moves GPU memory directly),
+    the host under the gloo backend (CPU tests; rehearsals of several ranks on one GPU)."""
+    return torch.device("cpu") if dist.get_backend(group) == "gloo" else dev
+
+
 def gather_samples(tensors, group=None):
     """tensors: dict name -> tensor with the same leading length n (this rank's samples),
     all on this rank's device.  Returns dict name -> tensor holding every rank's samples,
@@ -23,7 +29,8 @@ def gather_samples(tensors, group=None):
     world = dist.get_world_size(group)
     names = sorted(tensors)
     n = int(tensors[names[0]].shape[0]) if names else 0
-    dev = tensors[names[0]].device
+    own = tensors[names[0]].device
+    dev = _comm_device(own, group)
     counts = torch.zeros(world, dtype=torch.int64, device=dev)
     mine = torch.tensor([n], dtype=torch.int64, device=dev)
     dist.all_gather_into_tensor(counts, mine, group=group)
@@ -37,7 +44,7 @@ def gather_samples(tensors, group=None):
         buf = torch.empty((world * nmax,) + tuple(t.shape[1:]), dtype=t.dtype, device=dev)
         dist.all_gather_into_tensor(buf, pad, group=group)
         buf = buf.view((world, nmax) + tuple(t.shape[1:]))
-        out[name] = torch.cat([buf[r, :counts_h[r]] for r in range(world)], dim=0)
+        out[name] = torch.cat([buf[r, :counts_h[r]] for r in range(world)], dim=0).to(own)
     return out
 
 
@@ -73,7 +80,8 @@ def gather_packed(t, n_cells, group=None):
     planes are not sent; the receiver rebuilds them from the stones (SelfPlayEngine.unpack_states)."""
     world = dist.get_world_size(group)
     rows = pack_samples(t)
-    n, dev = int(rows.shape[0]), rows.device
+    n, own = int(rows.shape[0]), rows.device
+    dev = _comm_device(own, group)
     counts = torch.zeros(world, dtype=torch.int64, device=dev)
     dist.all_gather_into_tensor(counts, torch.tensor([n], dtype=torch.int64, device=dev), group=group)
     counts_h = counts.cpu().tolist()
@@ -83,7 +91,7 @@ def gather_packed(t, n_cells, group=None):
     buf = torch.empty((world * nmax, rows.shape[1]), dtype=torch.uint8, device=dev)
     dist.all_gather_into_tensor(buf, pad, group=group)
     buf = buf.view(world, nmax, rows.shape[1])
-    return unpack_samples(torch.cat([buf[r, :counts_h[r]] for r in range(world)], dim=0), n_cells)
+    return unpack_samples(torch.cat([buf[r, :counts_h[r]] for r in range(world)], dim=0).to(own), n_cells)
 
 
 def broadcast_weights(net, src=0, group=None):

@@ -154,6 +154,9 @@ def main():
                     help="upper bound of the untimed pre-roll steps that bring the slot population to steady state")
     ap.add_argument("--host-refill", action="store_true",
                     help="restart finished slots from the host between steps instead of the pipelined azg_selfplay_* calls")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="every rank uses GPU 0 and the exchange goes over gloo: runs the sharded code path with several "
+                         "processes on a one-GPU machine (RCCL refuses two ranks on one device); NOT a benchmark")
     ap.add_argument("--cnn", choices=["f16x3", "f32"], default="f16x3",
                     help="conv arithmetic: split-f16 MFMA (three products, f32 accumulate) or f32-input MFMA")
     args = ap.parse_args()
@@ -161,7 +164,7 @@ def main():
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = 0 if args.rehearse_on_one_gpu else int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     use_dist = world > 1 or "RANK" in os.environ
     if use_dist:
@@ -174,7 +177,10 @@ def main():
         saved_stdout = os.dup(1)
         os.dup2(2, 1)
         try:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            if args.rehearse_on_one_gpu:
+                dist.init_process_group("gloo", rank=rank, world_size=world)
+            else:
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
             dist.barrier()
             torch.cuda.synchronize()
         finally:
@@ -266,7 +272,8 @@ def main():
     launches, kernel_ms, evals = eng.profile()
     host = eng.host_timing()
 
-    stats = torch.tensor([dt, games, plies, evals, kernel_ms, launches, all_games, preroll], dtype=torch.float64, device=dev)
+    stats = torch.tensor([dt, games, plies, evals, kernel_ms, launches, all_games, preroll], dtype=torch.float64,
+                         device="cpu" if args.rehearse_on_one_gpu else dev)
     if use_dist:
         mx = stats.clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
@@ -289,7 +296,7 @@ def main():
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
             "dtype": "f16x3 (f32 operands split into two halves, three f16 MFMAs per product, f32 accumulate; tree in f64)" if args.cnn == "f16x3" else "f32",
-            "data": "synthetic",
+            "data": "synthetic" + (" (REHEARSAL: all ranks share GPU 0, exchange over gloo -- not a measurement)" if args.rehearse_on_one_gpu else ""),
             "config": {"workload": "%dx%d board %d-in-row, n_playout=%d, %d parallel self-play games per MI355X, "
                                    "random-init net (torch.manual_seed(0) default init), empty-board starts, "
                                    "c_puct=5, temp=1, Dirichlet(0.1) mix 0.25, tree reuse, finished slots refilled"

@@ -959,3 +959,63 @@ def test_two_wave_group_search_kernel_with_both_sets_live(az, oracle, n, B):
             boards[g].do_move(int(moves[g]))
     eng.close()
     ev.close()
+
+
+@pytest.mark.parametrize("n,k", [(3, 3), (4, 2), (5, 4), (6, 4), (7, 1), (8, 5), (9, 5), (11, 6), (13, 5), (15, 5), (16, 5), (16, 9)])
+def test_random_games_on_every_board_size_follow_the_oracle_rules(az, oracle, n, k):
+    """Board.do_move / game_end / current_state on random move sequences, 48 games per board size
+    stepping together through azg_board_step_batch until the oracle's board says each has ended:
+    ended flag, winner and all four planes after EVERY move must equal the oracle's (game.py:92-169),
+    including rows that wrap, both diagonals, lines longer than n_in_row, n_in_row below 3 (a line
+    may exist before the reference's stone-count threshold lets it count) and full boards."""
+    rng = np.random.RandomState(1000 * n + k)
+    nb, S = 48, n * n
+    seqs = [rng.permutation(S) for _ in range(nb)]
+    # half of the games are steered: one colour fills a line early so that wins in every
+    # direction occur at all (uniformly random games on large boards mostly end as ties)
+    for i in range(0, nb, 2):
+        r0, c0 = rng.randint(0, n), rng.randint(0, n)
+        dr, dc = [(0, 1), (1, 0), (1, 1), (1, -1)][(i // 2) % 4]
+        line = [(r0 + j * dr) * n + (c0 + j * dc) for j in range(k + 1)
+                if 0 <= r0 + j * dr < n and 0 <= c0 + j * dc < n]
+        rest = [int(m) for m in seqs[i] if m not in line]
+        mixed, a, b = [], list(line), rest
+        while a or b:                                    # the line's cells go to the player who moves first
+            if a:
+                mixed.append(a.pop(0))
+            elif b:
+                mixed.append(b.pop(0))
+            if b:
+                mixed.append(b.pop(0))
+        seqs[i] = np.array(mixed)
+    boards = []
+    for _ in range(nb):
+        ob = oracle.OracleBoard(n, n, k)
+        ob.init_board()
+        boards.append(ob)
+    eng = az.SelfPlayEngine(n, k, 1, 1, prior_mode=az.PRIOR_HASH)
+    st = np.zeros((nb, 2, 4), dtype=np.uint64)
+    ply = np.zeros(nb, dtype=np.int32)
+    last = np.full(nb, -1, dtype=np.int32)
+    alive = np.ones(nb, dtype=bool)
+    outcomes = set()
+    for t in range(S):
+        act = np.nonzero(alive)[0]
+        if not len(act):
+            break
+        sub_st, sub_ply, sub_last = (np.ascontiguousarray(x[act]) for x in (st, ply, last))
+        mv = np.array([seqs[i][t] for i in act], dtype=np.int32)
+        pl = np.full(len(act), 1 + t % 2, dtype=np.int32)
+        e, w, planes = eng.board_step_batch(sub_st, sub_ply, sub_last, mv, pl)
+        st[act], ply[act], last[act] = sub_st, sub_ply, sub_last
+        for j, i in enumerate(act):
+            boards[i].do_move(int(mv[j]))
+            oe, ow = boards[i].game_end()
+            assert (bool(e[j]), int(w[j]) if oe else -1) == (oe, ow if oe else -1), (n, k, i, t)
+            assert np.array_equal(planes[j], boards[i].current_state().astype(np.float32)), (n, k, i, t, "planes")
+            if oe:
+                alive[i] = False
+                outcomes.add(ow)
+    assert not alive.any()
+    assert len(outcomes) >= (1 if k == 1 else 2), outcomes
+    eng.close()
