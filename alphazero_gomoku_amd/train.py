@@ -303,16 +303,22 @@ def main(argv=None):
     ap.add_argument("--continuous", action="store_true",
                     help="never idle a slot: finished games are replaced at once, policy updates run between move steps")
     ap.add_argument("--slots", type=int, default=1024, help="game slots per GPU")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="every rank uses GPU 0 and the collectives go over gloo: runs the multi-rank code path on a "
+                         "one-GPU machine (RCCL refuses two ranks on one device); not a measurement")
     args = ap.parse_args(argv)
     os.environ.setdefault("NCCL_DEBUG", "WARN")            # keeps most of RCCL's start-up banner off stdout
     import torch
     import torch.distributed as dist
-    rank, world, local = 0, 1, int(os.environ.get("LOCAL_RANK", "0"))
+    rank, world, local = 0, 1, 0 if args.rehearse_on_one_gpu else int(os.environ.get("LOCAL_RANK", "0"))
     if "RANK" in os.environ:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if args.rehearse_on_one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         rank, world = dist.get_rank(), dist.get_world_size()
     torch.manual_seed(0)                                   # every rank starts from the same weights
     random.seed(1234)                                      # and samples the same mini-batches
@@ -354,7 +360,7 @@ def main(argv=None):
         print(json.dumps({"games": tp.games_played, "ranks": world, "seconds": dt, "games_per_s_incl_training": tp.games_played / dt,
                           "samples": int(sum(n for _, n, _, _ in log)), "policy_updates": tp.policy_updates,
                           "updates_per_batch": upb, "play_batch": args.play_batch, "continuous": bool(args.continuous),
-                          "slots_per_gpu": tp.engine.B,
+                          "slots_per_gpu": tp.engine.B, "rehearsal_on_one_gpu": bool(args.rehearse_on_one_gpu),
                           "first_loss": losses[0] if losses else None, "last_loss": losses[-1] if losses else None,
                           "lr_multiplier": tp.lr_multiplier, "best_win_ratio": tp.best_win_ratio,
                           "timer": "starts after one optimiser step on a scratch net (library initialisation), ends after the last update"}))
