@@ -186,6 +186,7 @@ struct DevState {
     float *bP; int *bN; double *bQ; int *bChild; unsigned *bMeta;   // [n_big][2][cap_big]
     unsigned long long *arena_stats;   // [2] moves into a large arena | trees dropped because none was free
     unsigned char *cur;            // [B]
+    int rr_cap;                    // LDS entries of a re-root's work stack (128 .. kRerootStackMax)
     long long *evals;              // [B] leaf evaluations that needed priors (profiling)
     // per-game training samples, two banks per slot: the game in progress records into bank
     // s_bank[g]; a slot restarted on the device (pipelined self-play) flips the bank, so the

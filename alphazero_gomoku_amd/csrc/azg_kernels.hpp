@@ -358,70 +358,139 @@ __device__ inline void fresh_root(const DevState &st, int g, int arena)
     st.cur[g] = (unsigned char)arena;
 }
 
-// MCTS.update_with_move (mcts_alphaZero.py:183-192): the subtree below child edge
-// `c` of the old arena becomes the whole tree of the new arena.  Breadth-first copy;
-// an edge's child field holds the OLD block address until the scan reaches it.
+// MCTS.update_with_move (mcts_alphaZero.py:183-192): the subtree below child edge `c` of the old
+// arena becomes the whole tree of the new arena.
+//
+// Work list: the expanded nodes whose child block is still to be copied, as (new edge index, old
+// block, number of children), a stack in LDS (rr: three rows of rr_cap ints, this wave's own).  A
+// round pops up to RB nodes, gives their blocks the next free edges of the new arena, has the loads
+// of all RB blocks in flight together and stores them; children that are expanded themselves go
+// onto the stack, the others are final.  One memory round trip per RB nodes; nothing written here
+// is read back.  An edge's child field is written exactly once: -1 with its block when it is a
+// leaf, the new block address when its node is popped.
+// When the stack is full its older half moves to the unused TAIL of the new arena (entry i at index
+// cap-1-i of the N / child / meta arrays) and comes back when the LDS part has run empty.  The tail
+// cannot meet the copied edges: every pending node still adds at least one edge, so
+// edges written + pending nodes <= edges of the finished copy <= cap.
+// The order in which nodes are copied (depth first here) decides only where blocks lie, not what
+// the tree holds: children of a node stay contiguous and in ascending action order.
 #ifndef AZG_REROOT_BLOCKS
-#define AZG_REROOT_BLOCKS 4     // measured at 8x8: 8 blocks +0.013 ms per move step, 16 blocks +0.053 ms
+#define AZG_REROOT_BLOCKS 8     // nodes per round (measured at 8x8: 4 -> +0.05 ms per move step, 16 -> +0.15 ms)
 #endif
-__device__ inline void wave_reroot(const DevState &st, int g, int c, int lane)
+constexpr int kRerootStackMax = 512;            // LDS entries per wave (3 ints each)
+
+__device__ inline void wave_reroot(const DevState &st, int g, int c, int lane, int *rr, int rr_cap)
 {
-    constexpr int RB = AZG_REROOT_BLOCKS;                     // child blocks copied per round (divides 64)
+    constexpr int RB = AZG_REROOT_BLOCKS;
     const int oa = st.cur[g], na = oa ^ 1;
     const TreeView o = tree_view(st, g, oa), n = tree_view(st, g, na);
+    const int cap = arena_cap(st, g);
+    int *se = rr, *so = rr + rr_cap, *sk = rr + 2 * rr_cap;
+    const int rc = o.child[c];
+    const unsigned rmeta = o.meta[c];
     if (lane == 0) {
-        n.P[0] = o.P[c]; n.N[0] = o.N[c]; n.Q[0] = o.Q[c]; n.child[0] = o.child[c]; n.meta[0] = o.meta[c];
+        n.P[0] = o.P[c]; n.N[0] = o.N[c]; n.Q[0] = o.Q[c]; n.meta[0] = rmeta;
+        if (rc < 0) n.child[0] = -1;
+        else { se[0] = 0; so[0] = rc; sk[0] = meta_k(rmeta); }
     }
-    wg_fence();
-    int freep = 1, scan = 0;
-    while (scan < freep) {
-        const int chunk_end = min(scan + WAVE, freep);
-        const int e = scan + lane;
-        int oc = -1, k = 0;
-        if (e < chunk_end) { oc = n.child[e]; k = meta_k(n.meta[e]); }
-        const int kk_l = oc >= 0 ? k : 0;
-        // destination of every queued node's child block: exclusive prefix sum of the block sizes
-        int incl = kk_l;
-#pragma unroll
-        for (int off = 1; off < WAVE; off <<= 1) {
-            const int v = __shfl_up(incl, off);
-            if (lane >= off) incl += v;
-        }
-        const int dst_l = freep + incl - kk_l;
-        const int total = __shfl(incl, WAVE - 1);
-        if (oc >= 0) n.child[e] = dst_l;
-        // copy RB child blocks per round: their loads are all in flight before the first store,
-        // so a round costs one memory round trip instead of RB
-        const u64 have = __ballot(oc >= 0);
-        for (int g0 = 0; g0 < WAVE; g0 += RB) {
-            if (!((have >> g0) & ((1ULL << RB) - 1ULL))) continue;
-            float p4[RB]; int n4[RB], c4[RB]; double q4[RB]; unsigned m4[RB]; int d4[RB]; bool on4[RB];
-#pragma unroll
-            for (int u = 0; u < RB; u++) {
-                const int ob = __shfl(oc, g0 + u), kk = __shfl(kk_l, g0 + u);
-                d4[u] = __shfl(dst_l, g0 + u);
-                on4[u] = ob >= 0 && lane < kk;          // blocks hold at most 64 children per pass
-                if (on4[u]) {
-                    p4[u] = o.P[ob + lane]; n4[u] = o.N[ob + lane]; q4[u] = o.Q[ob + lane];
-                    c4[u] = o.child[ob + lane]; m4[u] = o.meta[ob + lane];
-                }
-                // blocks wider than a wave (boards above 8x8): the remaining children
-                if (ob >= 0)
-                    for (int i = lane + WAVE; i < kk; i += WAVE) {
-                        n.P[d4[u] + i] = o.P[ob + i]; n.N[d4[u] + i] = o.N[ob + i]; n.Q[d4[u] + i] = o.Q[ob + i];
-                        n.child[d4[u] + i] = o.child[ob + i]; n.meta[d4[u] + i] = o.meta[ob + i];
-                    }
+    wave_sync();
+    int sp = rc >= 0 ? 1 : 0;          // entries on the LDS stack
+    int spilled = 0;                   // entries in the arena tail
+    int freep = 1;
+
+    // children of a copied piece that are expanded themselves: onto the stack (at most 64)
+    auto push = [&](bool on, int e_new, int oc, int k) {
+        if (sp + WAVE > rr_cap) {
+            // the older half of the stack moves to the tail, the newer half moves down
+            const int h = rr_cap / 2;
+            for (int i = lane; i < h; i += WAVE) {
+                const int at = cap - 1 - (spilled + i);
+                n.N[at] = se[i]; n.child[at] = so[i]; n.meta[at] = (unsigned)sk[i];
             }
-#pragma unroll
-            for (int u = 0; u < RB; u++)
-                if (on4[u]) {
-                    n.P[d4[u] + lane] = p4[u]; n.N[d4[u] + lane] = n4[u]; n.Q[d4[u] + lane] = q4[u];
-                    n.child[d4[u] + lane] = c4[u]; n.meta[d4[u] + lane] = m4[u];
-                }
+            wave_sync();
+            for (int i0 = 0; i0 < sp - h; i0 += WAVE) {
+                const int i = i0 + lane;
+                int a = 0, b = 0, d = 0;
+                if (i < sp - h) { a = se[h + i]; b = so[h + i]; d = sk[h + i]; }
+                wave_sync();
+                if (i < sp - h) { se[i] = a; so[i] = b; sk[i] = d; }
+                wave_sync();
+            }
+            spilled += h;
+            sp -= h;
         }
-        freep += total;
-        wg_fence();
-        scan = chunk_end;
+        const u64 m = __ballot(on);
+        if (on) {
+            const int at = sp + __popcll(m & ((1ULL << lane) - 1ULL));
+            se[at] = e_new; so[at] = oc; sk[at] = k;
+        }
+        sp += __popcll(m);
+        wave_sync();
+    };
+
+    while (sp > 0 || spilled > 0) {
+        if (sp == 0) {
+            // the LDS part ran empty: the newest entries of the tail come back
+            const int m = min(spilled, rr_cap / 2);
+            wg_fence();
+            for (int i = lane; i < m; i += WAVE) {
+                const int at = cap - 1 - (spilled - m + i);
+                se[i] = n.N[at]; so[i] = n.child[at]; sk[i] = (int)n.meta[at];
+            }
+            wave_sync();
+            spilled -= m;
+            sp = m;
+        }
+        const int m = min(RB, sp);
+        int e4[RB], ob4[RB], kk4[RB], d4[RB];
+#pragma unroll
+        for (int u = 0; u < RB; u++) {
+            const int at = sp - 1 - (u < m ? u : 0);
+            e4[u] = se[at]; ob4[u] = u < m ? so[at] : -1; kk4[u] = u < m ? sk[at] : 0;
+            d4[u] = freep;
+            freep += kk4[u];
+        }
+        sp -= m;
+        wave_sync();                                   // the popped entries are read before anything is pushed over them
+        if (lane < m) {
+            int e = e4[0], d = d4[0];
+#pragma unroll
+            for (int u = 1; u < RB; u++) if (lane == u) { e = e4[u]; d = d4[u]; }
+            n.child[e] = d;
+        }
+        float p4[RB]; int n4[RB], c4[RB]; double q4[RB]; unsigned m4[RB]; bool on4[RB];
+#pragma unroll
+        for (int u = 0; u < RB; u++) {
+            on4[u] = lane < kk4[u];                    // the first 64 children of the block
+            if (on4[u]) {
+                p4[u] = o.P[ob4[u] + lane]; n4[u] = o.N[ob4[u] + lane]; q4[u] = o.Q[ob4[u] + lane];
+                c4[u] = o.child[ob4[u] + lane]; m4[u] = o.meta[ob4[u] + lane];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < RB; u++) {
+            if (u >= m) break;                         // wave-uniform
+            if (on4[u]) {
+                const int at = d4[u] + lane;
+                n.P[at] = p4[u]; n.N[at] = n4[u]; n.Q[at] = q4[u]; n.meta[at] = m4[u];
+                if (c4[u] < 0) n.child[at] = -1;
+            }
+            push(on4[u] && c4[u] >= 0, d4[u] + lane, c4[u], (int)meta_k(m4[u]));
+            // blocks wider than a wave (boards above 8x8): the remaining children
+            for (int i0 = WAVE; i0 < kk4[u]; i0 += WAVE) {
+                const int i = i0 + lane;
+                const bool on = i < kk4[u];
+                int cc = -1;
+                unsigned mm = 0;
+                if (on) {
+                    const int from = ob4[u] + i, at = d4[u] + i;
+                    cc = o.child[from]; mm = o.meta[from];
+                    n.P[at] = o.P[from]; n.N[at] = o.N[from]; n.Q[at] = o.Q[from]; n.meta[at] = mm;
+                    if (cc < 0) n.child[at] = -1;
+                }
+                push(on && cc >= 0, d4[u] + i, cc, (int)meta_k(mm));
+            }
+        }
     }
     if (lane == 0) { st.used[g] = freep; st.cur[g] = (unsigned char)na; }
 }
@@ -469,6 +538,7 @@ __global__ __launch_bounds__(256) void advance_kernel(DevState st, double temp, 
     __shared__ double s_e[4][MAXS];
     __shared__ double s_c[4][MAXS];
     __shared__ u64 s_bbw[4][2][MAXW];
+    __shared__ int s_rr[4][3 * kRerootStackMax];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int g = blockIdx.x * 4 + wave;
     if (g >= st.B) return;
@@ -585,7 +655,7 @@ __global__ __launch_bounds__(256) void advance_kernel(DevState st, double temp, 
         if (ended || child_idx < 0) {
             if (lane == 0) fresh_root(st, g, st.cur[g]);      // reset_player / unknown move
         } else {
-            wave_reroot(st, g, base + child_idx, lane);
+            wave_reroot(st, g, base + child_idx, lane, s_rr[wave], st.rr_cap);
             wave_fit_arena(st, g, (flags & ADV_BOARD) ? ply + 1 : ply, lane);
         }
     }
@@ -617,6 +687,7 @@ __global__ __launch_bounds__(256) void advance_kernel(DevState st, double temp, 
 // MCTS.update_with_move alone (board untouched): moves[g] >= 0 re-root, -1 fresh, -2 skip.
 __global__ __launch_bounds__(256) void reroot_kernel(DevState st, const int *moves)
 {
+    __shared__ int s_rr[4][3 * kRerootStackMax];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int g = blockIdx.x * 4 + wave;
     if (g >= st.B) return;
@@ -635,7 +706,7 @@ __global__ __launch_bounds__(256) void reroot_kernel(DevState st, const int *mov
         }
     if (child_idx < 0) { if (lane == 0) fresh_root(st, g, st.cur[g]); }
     else {
-        wave_reroot(st, g, base + child_idx, lane);
+        wave_reroot(st, g, base + child_idx, lane, s_rr[wave], st.rr_cap);
         wave_fit_arena(st, g, st.ply[g], lane);
     }
 }

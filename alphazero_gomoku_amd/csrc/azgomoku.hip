@@ -443,6 +443,13 @@ static int create_impl(azg_handle *h)
     DevState &st = h->st;
     st.N = N; st.S = S; st.NW = (S + 63) / 64; st.n_in_row = c.n_in_row; st.B = B;
     st.prior_mode = c.prior_mode; st.n_playout = c.n_playout; st.c_puct = c.c_puct;
+    {
+        // work stack of the re-root copy: AZG_REROOT_STACK in the environment makes it small, so that
+        // tests drive the path that parks the stack's older half in the arena tail
+        const char *e = getenv("AZG_REROOT_STACK");
+        const int want = e ? atoi(e) : kRerootStackMax;
+        st.rr_cap = want < 128 ? 128 : (want > kRerootStackMax ? kRerootStackMax : want);
+    }
     st.cap = 1 + h->cfg.arena_nodes * S;
     const size_t E = (size_t)B * 2 * st.cap;
     int rc;
