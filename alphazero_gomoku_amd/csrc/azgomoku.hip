@@ -1318,10 +1318,15 @@ extern "C" int azg_selfplay_begin(azg_handle *h, double temp, uint32_t seed0, in
     return AZG_OK;
 }
 
-// the drain of the games that ended in the step just taken, behind the search already enqueued
+// The drain of the games that ended in the step just taken.  It goes to the copy stream: the advance
+// that finished those games is complete (the host has its mirror), so the drain runs beside the
+// search already in flight instead of between that search and the next advance.  The next step's
+// noise upload follows it on the copy stream and the next advance waits for that upload, so by the
+// time the host sees the next mirror the drained tuples are in place.
 static int sp_enqueue_drain(azg_handle *h)
 {
     auto &sp = h->sp;
+    hipStream_t ds_ = sp.copy_stream;
     const int B = h->cfg.n_games, S = h->st.S;
     const size_t cap = (size_t)B * S;
     int *mg = sp.h_map + (size_t)sp.par * 3 * cap, *mt = mg + cap, *ma = mt + cap;
@@ -1350,11 +1355,11 @@ static int sp_enqueue_drain(azg_handle *h)
     void *dst, *dla;
     if ((rc = scratch_get(h, 32 + sp.par * 2, (size_t)n * 2 * MAXW * sizeof(u64), &dst))) return rc;
     if ((rc = scratch_get(h, 33 + sp.par * 2, (size_t)n * sizeof(int), &dla))) return rc;
-    HIPCHK(h, hipMemcpyAsync(dg, mg, (size_t)n * sizeof(int), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipMemcpyAsync(dt, mt, (size_t)n * sizeof(int), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipMemcpyAsync(da, ma, (size_t)n * sizeof(int), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipMemcpyAsync(di, mi, (size_t)n * sizeof(long long), hipMemcpyHostToDevice, h->stream));
-    hipLaunchKernelGGL(drain_kernel, dim3(n), dim3(64), 0, h->stream, h->st, n, (const int *)dg, (const int *)dt,
+    HIPCHK(h, hipMemcpyAsync(dg, mg, (size_t)n * sizeof(int), hipMemcpyHostToDevice, ds_));
+    HIPCHK(h, hipMemcpyAsync(dt, mt, (size_t)n * sizeof(int), hipMemcpyHostToDevice, ds_));
+    HIPCHK(h, hipMemcpyAsync(da, ma, (size_t)n * sizeof(int), hipMemcpyHostToDevice, ds_));
+    HIPCHK(h, hipMemcpyAsync(di, mi, (size_t)n * sizeof(long long), hipMemcpyHostToDevice, ds_));
+    hipLaunchKernelGGL(drain_kernel, dim3(n), dim3(64), 0, ds_, h->st, n, (const int *)dg, (const int *)dt,
                        (const int *)da, (const long long *)di, (float *)ds, (double *)dp, (float *)dz,
                        (long long *)dgid, (int *)dply, (u64 *)dst, (int *)dla);
     HIPCHK(h, hipGetLastError());
@@ -1477,7 +1482,8 @@ extern "C" int azg_selfplay_end(azg_handle *h, int *samples_ready)
     HIPCHK(h, hipSetDevice(h->cfg.device));
     auto &sp = h->sp;
     sp.active = false;
-    int rc = refresh_mirrors(h);                    // waits for the search in flight and the last drain
+    int rc = refresh_mirrors(h);                    // waits for the search in flight
+    HIPCHK(h, hipStreamSynchronize(sp.copy_stream));   // and for the last drain
     sp.ready_n = sp.pend_n; sp.ready_games = sp.pend_games; sp.ready_par = sp.par ^ 1;
     sp.pend_n = sp.pend_games = 0;
     if (samples_ready) *samples_ready = sp.ready_n;
