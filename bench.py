@@ -61,9 +61,12 @@ def random_init_params(n, device):
     return [sd[k].to(device) for k in PARAM_ORDER]
 
 
-def cpu_baseline(n, k, n_playout, params_np, seconds_hint=25.0):
+def cpu_baseline(n, k, n_playout, params_np, plies_per_game=None):
     """The CPU oracle (C port of the reference's mcts_alphaZero + numpy-net path) timed on the
-    host cores: one whole game per thread, float32 net."""
+    host cores: one whole game per thread, float32 net.  Workloads whose whole games would take
+    minutes on the host (large boards, many playouts) are sampled by searches instead: every thread
+    runs two successive moves' searches of one game, and games/s follows from the playout rate and
+    the mean game length of the GPU run."""
     from oracle import az_oracle
     az_oracle.build()
     try:
@@ -73,6 +76,29 @@ def cpu_baseline(n, k, n_playout, params_np, seconds_hint=25.0):
     # a one-GPU share of the host is 16 cores; os.cpu_count() shows the whole machine
     threads = max(1, min(16, usable))
     net = az_oracle.OracleNet(n, n, params_np, precise=False)
+    if n * n * n_playout > 2 * 64 * 400:
+        from concurrent.futures import ThreadPoolExecutor
+
+        def searches(seed):
+            ob = az_oracle.OracleBoard(n, n, k)
+            ob.init_board()
+            t = az_oracle.OracleMCTS("net", c_puct=5, n_playout=n_playout, net=net)
+            for _ in range(2):
+                acts, vis, _, _, _ = t.get_move_probs(ob, temp=1.0)
+                mv = int(acts[(int(np.argmax(vis)) + seed) % len(acts)])
+                t.update_with_move(mv)
+                ob.do_move(mv)
+            return 2 * n_playout
+        t0 = time.time()
+        with ThreadPoolExecutor(threads) as ex:                      # the oracle's C code runs without the GIL
+            done = sum(ex.map(searches, range(threads)))
+        dt = time.time() - t0
+        rate = done / dt
+        return {"value": rate / (n_playout * plies_per_game) if plies_per_game else None, "unit": "games/s", "cores": threads,
+                "kind": "port", "playouts_per_s": rate, "nproc": os.cpu_count(), "cores_usable": usable,
+                "sample": "%d searches of %d playouts (two successive moves of one game per thread, tree re-used) in %.1f s; "
+                          "games/s = playout rate / (n_playout x %.1f plies per game of the GPU run); C restatement of the "
+                          "reference's Python path, float32 net" % (2 * threads, n_playout, dt, plies_per_game or float("nan"))}
     t0 = time.time()
     total_plies, plies, _ = az_oracle.self_play_many(n, k, net, 5.0, n_playout, 1.0, 0, threads, threads)
     dt = time.time() - t0
@@ -333,7 +359,7 @@ def main():
                                                  "pointer chasing inside the fused launch" % (tree_bytes / 1e3)}
         if world == 1 and not args.no_cpu_baseline:
             params_np = [p.cpu().numpy() for p in params]
-            out["cpu_baseline"] = cpu_baseline(n, k, args.playouts, params_np)
+            out["cpu_baseline"] = cpu_baseline(n, k, args.playouts, params_np, plies_per_game)
             if drained:
                 from oracle import az_oracle
                 out["visit_l1_vs_cpu"] = visit_l1_vs_cpu(az, az_oracle, n, k, args.playouts, params, params_np, drained[-1],

@@ -305,6 +305,22 @@ def test_trees_that_outgrow_their_arena_move_to_a_large_one(az, oracle):
     eng.close()
 
 
+@pytest.mark.parametrize("n,k,npo", [(8, 5, 1500), (15, 5, 600)])
+def test_reroot_with_a_small_work_stack(az, oracle, n, k, npo, monkeypatch):
+    """MCTS.update_with_move (mcts_alphaZero.py:183-192): the subtree copy keeps its work list of
+    expanded nodes in LDS and parks the older half in the arena tail when that is full.  With the
+    smallest stack (AZG_REROOT_STACK=128, read by azg_create) and large trees the parking path runs on
+    nearly every move; the kept statistics must still equal the oracle's, visit for visit, Q for Q --
+    on 15x15 with child blocks wider than a wave."""
+    monkeypatch.setenv("AZG_REROOT_STACK", "128")
+    eng = az.SelfPlayEngine(n, k, npo, 2, prior_mode=az.PRIOR_HASH)
+    monkeypatch.delenv("AZG_REROOT_STACK")
+    eng.reset_games()
+    plies = _forced_line(az, oracle, eng, "hash", n, k, npo, 10, (0, 1))
+    assert plies >= 5
+    eng.close()
+
+
 def test_peaked_prior_over_consecutive_moves(az, oracle):
     """A prior that puts 15/16 on one move, followed for a whole game: the root keeps almost all
     earlier visits (ten times n_playout after a dozen moves) and the default arena must cope."""
