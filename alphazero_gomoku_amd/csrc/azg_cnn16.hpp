@@ -56,6 +56,9 @@ __device__ inline void split2_f16(float v0, float v1, unsigned &h, unsigned &l)
 // beside the operands in the 256 registers a wave has when eight waves share a CU).  Every kernel of
 // a board size -- search, evaluation -- uses the same value: the grouping of the head convolutions'
 // partial sums follows it, and a position must evaluate to the same bits wherever it is evaluated.
+#ifndef AZG_MFMA_ROTATE
+#define AZG_MFMA_ROTATE 0     // 1: the k-step's products are issued accumulator after accumulator in rotation
+#endif
 #ifndef AZG_CW1
 #define AZG_CW1 2
 #endif
@@ -335,6 +338,20 @@ __device__ inline void conv3x3_f16(const half8 *wp, WRing<RING, CW> &ring, const
             if (ks + RING < KS) { ring.ah[ca][c] = wrow[c][(size_t)(ks + RING) * 128]; ring.al[ca][c] = wrow[c][(size_t)(ks + RING) * 128 + kWLo]; }
 #endif
         }
+#if AZG_MFMA_ROTATE
+        // the three products of a k-step go round the accumulators instead of queueing behind each
+        // other on one (same sums in the same order per accumulator)
+#pragma unroll
+        for (int pr = 0; pr < (XLO ? 3 : 2); pr++)
+#pragma unroll
+            for (int i = 0; i < PT; i++)
+#pragma unroll
+                for (int c = 0; c < CW; c++) {
+                    if (pr == 0) acc[c][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[c], bh[cb][i], ks == 0 ? zacc : acc[c][i], 0, 0, 0);
+                    if (pr == 1) acc[c][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[c], bh[cb][i], acc[c][i], 0, 0, 0);
+                    if (pr == 2) acc[c][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[c], bl[cb][i], acc[c][i], 0, 0, 0);
+                }
+#else
 #pragma unroll
         for (int i = 0; i < PT; i++)
 #pragma unroll
@@ -343,6 +360,7 @@ __device__ inline void conv3x3_f16(const half8 *wp, WRing<RING, CW> &ring, const
                 acc[c][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[c], bh[cb][i], acc[c][i], 0, 0, 0);
                 if (XLO) acc[c][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[c], bl[cb][i], acc[c][i], 0, 0, 0);
             }
+#endif
         // Issue order inside the k-step: the loads of later k-steps and their address
         // arithmetic are spread between this step's MFMAs (an MFMA occupies the matrix pipe for
         // 32 cycles but the issue port for 8).  Left alone the scheduler sinks each load to
