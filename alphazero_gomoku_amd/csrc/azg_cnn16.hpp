@@ -129,7 +129,7 @@ struct Cnn16Geom {
     // One-leaf kernels (T == 1): the fully connected layers run on the VALU over the NON-ZERO head
     // outputs only.  Wave w owns the inputs k = 4*i + w; its (k, x) pairs sit in lists behind the
     // head partials, the per-wave partial sums in the (by then dead) head-partial region.
-    static constexpr bool SPARSE_FC = T_ == 1;
+    static constexpr bool SPARSE_FC = T_ == 1 && N_ > 8;      // (one-leaf builds of the small boards keep the MFMA layers)
     static constexpr int PART_OFF = 0;                        // FC partials [4 waves][NOUT][T] (HP is dead by then)
     static constexpr int SPP_OFF = 0;                         // sparse FC: policy partials [4 waves][256]
     static constexpr int SPV_OFF = 1024;                      // sparse FC: value partials [4 waves][4 lane groups][64]

@@ -266,7 +266,9 @@ static bool pick_search(int N, int mode, int cnn_mode, SearchLaunch *out)
 #ifdef AZG_ONLY8                 // experiment builds: the 8x8 split-f16 kernels only (compiles in a third of the time)
     if (N != 8 || !f16) return false;
     *out = net_launch<8, AZG_T8, true>();
+#if AZG_OCC8 == 2 && AZG_T8 == 2
     out->fn = search_kernel_f16_8x8;
+#endif
     return true;
 #elif defined(AZG_ONLY15)        // experiment builds: 15x15 only
     if (N != 15 || !f16) return false;
