@@ -36,13 +36,22 @@ class TrainPipeline:
                       (they see new weights from their next move on), and the policy updates of batch k
                       are issued between the move steps of batch k+1.
     rng               source of the mini-batch draw (random.sample): a private random.Random by
-                      default; pass the `random` module for the reference's global stream."""
+                      default; pass the `random` module for the reference's global stream.
+    max_lr_multiplier the multiplier is raised (x1.5) only while it is below this; 10 is the reference's
+                      rule (train.py:199), under which it reaches 11.39.  With one game per update and a
+                      3000-tuple buffer (the reference's configuration) the KL it measures grows before
+                      that matters; with mini-batches drawn from hundreds of thousands of fresh tuples KL
+                      stays below kl_targ/2 until learn_rate x 11.39 = 0.023 wrecks the net (measured: every
+                      ReLU dead after seven updates, loss stuck at 5.15; a ceiling of 4, i.e. up to 5.06,
+                      still ends that way; 2, i.e. up to 2.25, learns: loss 5.14 -> 2.45 and 9 of 10 games
+                      won against the 1000-playout rollout player after 24 batches of 1024 games with 48
+                      updates each).  Default (None): 10 with play_batch_size 1, else 2."""
 
     def __init__(self, board_width=8, board_height=8, n_in_row=5, init_model=None, learn_rate=2e-3,
                  lr_multiplier=1.0, temp=1.0, n_playout=400, c_puct=5, buffer_size=10000, batch_size=512,
                  play_batch_size=1, epochs=5, kl_targ=0.02, check_freq=50, game_batch_num=1500,
                  n_parallel=1024, device=0, seed0=0, policy_value_net=None, pure_mcts_playout_num=1000,
-                 updates_per_batch=1, continuous=False, rng=None):
+                 updates_per_batch=1, continuous=False, rng=None, max_lr_multiplier=None):
         import torch
         from .net import PolicyValueNet
         self.board_width, self.board_height, self.n_in_row = board_width, board_height, n_in_row
@@ -56,6 +65,7 @@ class TrainPipeline:
         self.play_batch_size, self.epochs, self.kl_targ = play_batch_size, epochs, kl_targ
         self.check_freq, self.game_batch_num = check_freq, game_batch_num
         self.updates_per_batch, self.continuous = int(updates_per_batch), bool(continuous)
+        self.max_lr_multiplier = float(max_lr_multiplier) if max_lr_multiplier is not None else (10.0 if play_batch_size <= 1 else 2.0)
         self.best_win_ratio = 0.2                                            # train.py:88
         self.pure_mcts_playout_num = pure_mcts_playout_num
         self.policy_value_net = policy_value_net or PolicyValueNet(board_width, board_height, model_file=init_model,
@@ -178,7 +188,7 @@ class TrainPipeline:
                 break
         if kl > self.kl_targ * 2 and self.lr_multiplier > 0.05:
             self.lr_multiplier /= 1.5
-        elif kl < self.kl_targ / 2 and self.lr_multiplier < 10:
+        elif kl < self.kl_targ / 2 and self.lr_multiplier < getattr(self, "max_lr_multiplier", 10.0):
             self.lr_multiplier *= 1.5
         wz = winner_batch.double().cpu().numpy() if on_device else np.array(winner_batch)
         ov = old_v.double().cpu().numpy().flatten() if on_device else old_v.flatten()
@@ -303,6 +313,13 @@ def main(argv=None):
     ap.add_argument("--continuous", action="store_true",
                     help="never idle a slot: finished games are replaced at once, policy updates run between move steps")
     ap.add_argument("--slots", type=int, default=1024, help="game slots per GPU")
+    ap.add_argument("--final-eval", type=int, default=0,
+                    help="after the loop, play this many games against the rollout player (batched arena) and report the win ratio")
+    ap.add_argument("--lr-multiplier", type=float, default=1.0, help="start value of the adaptive learning-rate multiplier")
+    ap.add_argument("--max-lr-multiplier", type=float, default=None,
+                    help="the KL controller raises the multiplier only below this (the reference's rule is 10, which "
+                         "lets the learning rate reach 0.023: too much for mini-batches of fresh tuples from 1024 games; "
+                         "default 2, or 10 with --play-batch 1)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="every rank uses GPU 0 and the collectives go over gloo: runs the multi-rank code path on a "
                          "one-GPU machine (RCCL refuses two ranks on one device); not a measurement")
@@ -329,7 +346,8 @@ def main(argv=None):
                        play_batch_size=args.play_batch, epochs=args.epochs, check_freq=args.check_freq,
                        game_batch_num=(args.games + args.play_batch - 1) // args.play_batch, n_parallel=per_rank,
                        device=local, pure_mcts_playout_num=args.pure_playouts, updates_per_batch=upb,
-                       continuous=args.continuous)
+                       continuous=args.continuous, lr_multiplier=args.lr_multiplier,
+                       max_lr_multiplier=args.max_lr_multiplier)
     if world > 1:
         from . import dist as azdist
         azdist.broadcast_weights(tp.policy_value_net)
@@ -353,6 +371,11 @@ def main(argv=None):
     tp.run(on_batch=lambda i, n, loss, ent: log.append((i, n, loss, ent)))
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    final = None
+    if rank == 0 and args.final_eval > 0:
+        final = tp.policy_evaluate(args.final_eval, batched=True)
+    if world > 1:
+        dist.barrier()
     if rank == 0:
         if args.save:
             tp.policy_value_net.save_model(args.save)
@@ -362,7 +385,10 @@ def main(argv=None):
                           "updates_per_batch": upb, "play_batch": args.play_batch, "continuous": bool(args.continuous),
                           "slots_per_gpu": tp.engine.B, "rehearsal_on_one_gpu": bool(args.rehearse_on_one_gpu),
                           "first_loss": losses[0] if losses else None, "last_loss": losses[-1] if losses else None,
-                          "lr_multiplier": tp.lr_multiplier, "best_win_ratio": tp.best_win_ratio,
+                          "loss_curve": [round(losses[i], 3) for i in range(0, len(losses), max(1, len(losses) // 16))],
+                          "entropy_first_last": [tp.loss_history[0][1], tp.loss_history[-1][1]] if tp.loss_history else None,
+                          "win_ratio_vs_rollout_player": final, "rollout_playouts": tp.pure_mcts_playout_num,
+                          "lr_multiplier": tp.lr_multiplier, "max_lr_multiplier": tp.max_lr_multiplier, "best_win_ratio": tp.best_win_ratio,
                           "timer": "starts after one optimiser step on a scratch net (library initialisation), ends after the last update"}))
     if world > 1:
         dist.destroy_process_group()

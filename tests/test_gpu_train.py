@@ -297,3 +297,27 @@ def test_device_replay_buffer_matches_deque(az):
         s2, p2, z2 = [x.cpu().numpy() for x in buf.sample(m)]
         for i in range(m):
             assert np.array_equal(s2[i], want[i][0]) and np.array_equal(p2[i], want[i][1].astype(np.float32)) and z2[i] == want[i][2]
+
+
+def test_batched_training_loop_learns(az):
+    """The loop as a whole must LEARN when games are played in batches.  (At 8x8 with 1024 games per
+    batch the reference's controller, train.py:196-200, raised the learning rate to 0.023 while the KL
+    of mini-batches of fresh tuples stayed small; after seven updates every ReLU of the net was dead
+    and the loss sat at 1.0 + log(S).  The pipeline therefore stops raising the multiplier at 2 when
+    play_batch_size > 1.)  Here, small: the ceiling is the batched one, the loss falls, and the net
+    still tells positions apart."""
+    import torch
+    from alphazero_gomoku_amd.train import TrainPipeline
+    torch.manual_seed(0)
+    tp = TrainPipeline(board_width=6, board_height=6, n_in_row=4, n_playout=48, play_batch_size=256, n_parallel=256,
+                       batch_size=256, buffer_size=60000, game_batch_num=6, updates_per_batch=24, check_freq=0)
+    assert tp.max_lr_multiplier == 2.0
+    tp.run()
+    h = tp.loss_history
+    assert len(h) == 5 * 24 or len(h) == 6 * 24
+    first, last = np.mean([l for l, _ in h[:8]]), np.mean([l for l, _ in h[-8:]])
+    assert last < first - 0.3, (first, last)
+    assert tp.lr_multiplier <= 2.25
+    s, p, z = tp.data_buffer.take(tp.data_buffer.draw(256))
+    probs, v = tp.policy_value_net.policy_value(s)
+    assert float(probs.std(0).mean()) > 1e-3 and float(v.std()) > 1e-2      # not a constant function

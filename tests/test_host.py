@@ -255,6 +255,7 @@ def test_policy_update_schedule_matches_reference():
         tp.batch_size, tp.epochs, tp.learn_rate, tp.kl_targ = nb, 5, 2e-3, 0.02
         tp.lr_multiplier = sc["lr_multiplier_before"]
         tp.rank, tp.world, tp.policy_updates = 0, 1, 0
+        tp.max_lr_multiplier = 10.0                                   # the reference's ceiling (train.py:199)
         tp.data_buffer = ReplayBuffer(100, 3, rng=random.Random(3))
         tp.data_buffer.extend(np.zeros((nb, 4, 3, 3), dtype=np.float32), np.ones((nb, S)) / S,
                               np.array([float((-1) ** i) for i in range(nb)], dtype=np.float32))
@@ -265,6 +266,32 @@ def test_policy_update_schedule_matches_reference():
         assert tp.lr_multiplier == sc["lr_multiplier_after"], sc["name"]
         assert (loss, ent) == (sc["loss"], sc["entropy"]), sc["name"]
         assert abs(tp.last_kl - sc["kls"][sc["train_steps"] - 1]) < 1e-15
+
+
+def test_lr_multiplier_ceiling():
+    """The multiplier rises (x1.5) only while below max_lr_multiplier: 10 in the reference (so it can
+    reach 11.39), 2 by default when games are played in batches (so it stops at 2.25)."""
+    import random
+    from alphazero_gomoku_amd.train import TrainPipeline
+    from alphazero_gomoku_amd.train_data import ReplayBuffer
+
+    class Still:                                                      # a net whose policy never moves: KL = 0
+        def policy_value(self, state_batch):
+            n = len(state_batch)
+            return np.full((n, 9), 1.0 / 9), np.zeros((n, 1))
+
+        def train_step(self, s, p, w, lr):
+            return 1.0, 2.0
+    for ceiling, top in ((10.0, 1.5 ** 6), (2.0, 2.25), (1.0, 1.0)):
+        tp = TrainPipeline.__new__(TrainPipeline)
+        tp.batch_size, tp.epochs, tp.learn_rate, tp.kl_targ, tp.lr_multiplier = 8, 5, 2e-3, 0.02, 1.0
+        tp.rank, tp.world, tp.policy_updates, tp.max_lr_multiplier = 0, 1, 0, ceiling
+        tp.data_buffer = ReplayBuffer(100, 3, rng=random.Random(3))
+        tp.data_buffer.extend(np.zeros((16, 4, 3, 3), dtype=np.float32), np.ones((16, 9)) / 9, np.zeros(16, dtype=np.float32))
+        tp.policy_value_net = Still()
+        for _ in range(12):
+            tp.policy_update()
+        assert abs(tp.lr_multiplier - top) < 1e-12, (ceiling, tp.lr_multiplier)
 
 
 def test_train_step_matches_reference_on_cpu():
