@@ -182,6 +182,15 @@ class PolicyValueNet(object):
         probs, vals = self._engine().eval_batch(np.asarray(state_batch, dtype=np.float32))
         return probs, vals.reshape(-1, 1)
 
+    def policy_value_in_training(self, state_batch):
+        """(probs [B,S], value [B,1]) of a CUDA batch from the autograd module itself, for the KL
+        monitor inside policy_update: between two train steps of one update the engine's packed
+        copy of the weights is not refreshed (repacking them costs more than the train step); the
+        two forward passes agree to 1e-7."""
+        with torch.no_grad():
+            logp, v = self.policy_value_net(state_batch.to(device=self.device, dtype=torch.float32))
+        return torch.exp(logp), v.reshape(-1, 1)
+
     def policy_value_fn(self, board):
         """policy_value_net_pytorch.py:96-115: (zip(legal moves, probs), value)."""
         legal = board.availables

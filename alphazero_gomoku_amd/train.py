@@ -170,14 +170,16 @@ class TrainPipeline:
         state_batch, mcts_probs_batch, winner_batch = self.data_buffer.take(self._draw())
         net = self.policy_value_net
         on_device = torch.is_tensor(state_batch)
-        old_probs, old_v = net.policy_value(state_batch)
+        # (device batches: the KL monitor reads the autograd module, see policy_value_in_training)
+        policy_value = getattr(net, "policy_value_in_training", net.policy_value) if on_device else net.policy_value
+        old_probs, old_v = policy_value(state_batch)
         sl = slice(self.rank, None, self.world)                               # this rank's share of the mini-batch
         kl, loss, entropy = 0.0, float("nan"), float("nan")
         new_v = old_v
         for _ in range(self.epochs):
             loss, entropy = net.train_step(state_batch[sl], mcts_probs_batch[sl], winner_batch[sl],
                                            self.learn_rate * self.lr_multiplier)
-            new_probs, new_v = net.policy_value(state_batch)
+            new_probs, new_v = policy_value(state_batch)
             if on_device:
                 kl = float(torch.mean(torch.sum(old_probs.double() * (torch.log(old_probs.double() + 1e-10)
                                                                       - torch.log(new_probs.double() + 1e-10)), dim=1)))
