@@ -97,8 +97,25 @@ def gather_packed(t, n_cells, group=None):
 def broadcast_weights(net, src=0, group=None):
     """Replicate rank `src`'s parameters (476 KB at 8x8) after an optimiser step."""
     for t in net.param_tensors():
-        dist.broadcast(t, src=src, group=group)
+        c = t.to(_comm_device(t.device, group))
+        dist.broadcast(c, src=src, group=group)
+        if c is not t:
+            t.copy_(c)
     net.version += 1
+
+
+def broadcast_indices(idx, device, src=0, group=None):
+    """The mini-batch positions rank `src` drew, as a list, on every rank."""
+    t = torch.tensor(idx, dtype=torch.int64, device=_comm_device(device, group))
+    dist.broadcast(t, src=src, group=group)
+    return t.tolist()
+
+
+def max_over_ranks(x, device, group=None):
+    """The largest of the ranks' values of the float x."""
+    t = torch.tensor([x], dtype=torch.float64, device=_comm_device(device, group))
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return float(t[0])
 
 
 def allreduce_gradients(module, group=None):
@@ -111,7 +128,10 @@ def allreduce_gradients(module, group=None):
     if world == 1 or not params:
         return
     flat = torch.cat([p.grad.reshape(-1) for p in params])
+    own = flat.device
+    flat = flat.to(_comm_device(own, group))                 # gloo: through the host
     dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    flat = flat.to(own)
     flat /= world
     off = 0
     for p in params:

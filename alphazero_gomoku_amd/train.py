@@ -159,10 +159,8 @@ class TrainPipeline:
         idx = self.data_buffer.draw(self.batch_size)
         if self.world > 1:
             import torch
-            import torch.distributed as dist
-            t = torch.tensor(idx, dtype=torch.int64, device=torch.device("cuda", self.device))
-            dist.broadcast(t, src=0)
-            idx = t.tolist()
+            from . import dist as azdist
+            idx = azdist.broadcast_indices(idx, torch.device("cuda", self.device))
         return idx
 
     def policy_update(self):
@@ -209,10 +207,8 @@ class TrainPipeline:
         if self.world == 1:
             return kl
         import torch
-        import torch.distributed as dist
-        t = torch.tensor([kl], dtype=torch.float64, device=torch.device("cuda", self.device))
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        return float(t[0])
+        from . import dist as azdist
+        return azdist.max_over_ranks(kl, torch.device("cuda", self.device))
 
     # ---- train.py:216-276 --------------------------------------------------------------------
     def policy_evaluate(self, n_games=10, batched=False, seed0=0):
