@@ -382,6 +382,7 @@ def main(argv=None):
                           "samples": int(sum(n for _, n, _, _ in log)), "policy_updates": tp.policy_updates,
                           "updates_per_batch": upb, "play_batch": args.play_batch, "continuous": bool(args.continuous),
                           "slots_per_gpu": tp.engine.B, "rehearsal_on_one_gpu": bool(args.rehearse_on_one_gpu),
+                          "trees_moved_to_large_arena": tp.engine.arena_stats()[0], "trees_dropped_for_lack_of_one": tp.engine.arena_stats()[1],
                           "first_loss": losses[0] if losses else None, "last_loss": losses[-1] if losses else None,
                           "loss_curve": [round(losses[i], 3) for i in range(0, len(losses), max(1, len(losses) // 16))],
                           "entropy_first_last": [tp.loss_history[0][1], tp.loss_history[-1][1]] if tp.loss_history else None,
