@@ -34,7 +34,8 @@ class TrainPipeline:
                       True: the slots never idle -- a finished game is replaced at once, a batch is the
                       next play_batch_size games to finish, games in flight go on across policy updates
                       (they see new weights from their next move on), and the policy updates of batch k
-                      are issued between the move steps of batch k+1.
+                      are issued between the move steps of batch k+1 (one per move step on a single
+                      GPU; with several ranks all of them after the first move step, see _between_steps).
     rng               source of the mini-batch draw (random.sample): a private random.Random by
                       default; pass the `random` module for the reference's global stream.
     max_lr_multiplier the multiplier is raised (x1.5) only while it is below this; 10 is the reference's
@@ -102,7 +103,18 @@ class TrainPipeline:
         """Continuous mode: one pending policy update per move step, issued while the next search
         (already enqueued by the step) runs; after the last one the engine gets the new weights."""
         if self._todo:
-            self._todo.pop()()
+            if self.world > 1:
+                # Data-parallel updates hold collectives, and a collective's kernel gets no CU while a
+                # search launch is resident (two workgroups per CU fill the LDS and the registers): every
+                # one of the ~11 collectives of an update would wait for the end of a search.  So with
+                # several ranks the search in flight is allowed to finish once, and all pending updates
+                # run back to back before the next move step.
+                import torch
+                torch.cuda.synchronize(torch.device("cuda", self.device))
+                while self._todo:
+                    self._todo.pop()()
+            else:
+                self._todo.pop()()
             if not self._todo:
                 self._engine_version = self.policy_value_net.sync_engine(self.engine, self._engine_version)
 
