@@ -46,10 +46,14 @@ __device__ inline void lds_store(unsigned *p, unsigned v) { __hip_atomic_store(p
 // serves all waves of the CU through one queue, so whatever a wave wrote to LDS before its arrival
 // is there for a wave that has seen the arrival; the fences keep the compiler from moving LDS
 // accesses across.  Returns false when the workgroup is being abandoned.
+#ifndef AZG_DUAL_TREE_NAP
+#define AZG_DUAL_TREE_NAP 0   // 1: the tree waves poll their barrier and the net's acknowledgement at longer intervals
+#endif
 struct GroupSync {
     unsigned *ctr, *abort_word;
     unsigned target;
-    __device__ void init(unsigned *c, unsigned *a) { ctr = c; abort_word = a; target = 0; }
+    bool nap;
+    __device__ void init(unsigned *c, unsigned *a, bool n = false) { ctr = c; abort_word = a; target = 0; nap = n; }
     __device__ bool sync()
     {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -59,7 +63,7 @@ struct GroupSync {
         for (int spin = 0; spin < kSpinLimit; spin++) {
             if ((int)(lds_load(ctr) - target) >= 0) { ok = true; break; }
             if (lds_load(abort_word)) break;
-            __builtin_amdgcn_s_sleep(1);
+            if (nap) __builtin_amdgcn_s_sleep(6); else __builtin_amdgcn_s_sleep(1);
         }
         if (!ok) lds_store(abort_word, 1u);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -154,7 +158,9 @@ struct DualGeom : Cnn16Geom<N_, T_> {
 #ifndef AZG_FC_NT
 #define AZG_FC_NT 0          // 1: the sparse FC reads its weight rows with the non-temporal hint
 #endif
-#if AZG_FC_NT
+#if defined(AZG_EXP_NOFCLOAD)       // timing experiment (wrong results): the sparse FC reads one row over and over (vector-L1 hits)
+#define AZG_FC_LOAD(p) (*(wrow))
+#elif AZG_FC_NT
 #define AZG_FC_LOAD(p) __builtin_nontemporal_load(p)
 #else
 #define AZG_FC_LOAD(p) (*(p))
@@ -542,7 +548,7 @@ __device__ __forceinline__ void search_dual_body(DevState st)
     if (!any_live) return;
 
     GroupSync gs;
-    gs.init(&ctl->bar[net_group ? 0 : 1], &ctl->abort);
+    gs.init(&ctl->bar[net_group ? 0 : 1], &ctl->abort, AZG_DUAL_TREE_NAP && !net_group);
     Prof prof;
     prof.start(st.stamps, net_group ? 0 : 256);       // diagnostic builds: thread 0 times the net waves, thread 256 the tree waves
 

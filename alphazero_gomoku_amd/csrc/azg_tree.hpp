@@ -288,10 +288,15 @@ __device__ inline Descent wave_select(const DevState &st, const TreeView &t, GL 
 #pragma unroll
         for (int c = 0; c < CPL; c++) {
             const int i = lane + c * WAVE;
+            // x / 1.0 is x: where none of these 64 children has been visited (most nodes below the
+            // first levels) the double-precision division, the longest instruction sequence of the
+            // descent, is skipped for the whole wave
+            const bool any_visited = __ballot(i < K && n_[c] != 0) != 0ULL;
             if (i < K) {
                 const double p = UNIFORM_P ? 1.0 / (double)K : (double)p_[c];
                 // get_value (:82-83): c_puct * P * sqrt(Np) / (1 + n), left to right, then Q + u
-                const double u = ((st.c_puct * p) * sq) / (double)(1 + n_[c]);
+                const double num = (st.c_puct * p) * sq;
+                const double u = any_visited ? num / (double)(1 + n_[c]) : num;
                 const double s = q_[c] + u;
                 if (s > best) { best = s; bq = q_[c]; bidx = i; bchild = ch_[c]; bn = n_[c]; bmeta = mt_[c]; }
             }
