@@ -97,8 +97,15 @@ __device__ inline NetWeights opaque_weights(const NetWeights &w)
 // engines that run concurrently on separate streams pair up the same way.
 __device__ int g_matrix_gate[kGateWords];
 
+#ifndef AZG_GATE_TIMED
+#define AZG_GATE_TIMED 0      // 1: a waiting workgroup sleeps until the holder is due to release (see acquire)
+#endif
+#ifndef AZG_GATE_MARGIN
+#define AZG_GATE_MARGIN 384   // cycles before the expected release at which close polling starts
+#endif
 struct MatrixGate {
     int *word;
+    mutable int t_acq = 0, span = 0;       // thread 0: when it took the gate last (clock, low bits | 1), how long it held it
     __device__ void init(bool enabled)
     {
         // HW_REG_HW_ID bits: CU 11:8, SH 12, SE 15:13; HW_REG_XCC_ID bits 3:0
@@ -110,15 +117,40 @@ struct MatrixGate {
     __device__ void acquire() const
     {
         if (!word) return;
+#if AZG_GATE_TIMED
+        // The word holds the holder's acquire time.  Both workgroups of a CU do the same work inside
+        // the gate, so the holder is due to release about `span` cycles after it took the gate: sleep
+        // until shortly before, then poll closely.  (Polling closely all the time was measured slower.)
+        int now = (int)__builtin_amdgcn_s_memtime() | 1;
+        int old = atomicCAS(word, 0, now);
+        if (old == 0) { t_acq = now; return; }
+        const int due = old + span - AZG_GATE_MARGIN;
+        for (int guard = 0; guard < 4096; guard++) {
+            const int rem = due - (int)__builtin_amdgcn_s_memtime();
+            if (rem <= 0 || rem > (1 << 20)) break;
+            if (rem >= 1024) __builtin_amdgcn_s_sleep(15); else __builtin_amdgcn_s_sleep(2);
+        }
+        for (int tries = 0; tries < 3000; tries++) {
+            now = (int)__builtin_amdgcn_s_memtime() | 1;
+            if (atomicCAS(word, 0, now) == 0) { t_acq = now; return; }
+            if (tries < 64) __builtin_amdgcn_s_sleep(1); else __builtin_amdgcn_s_sleep(16);
+        }
+#else
         for (int tries = 0; tries < 2000; tries++) {
             if (atomicCAS(word, 0, 1) == 0) return;
             __builtin_amdgcn_s_sleep(16);
         }
+#endif
     }
     // thread 0 of the workgroup, after a workgroup barrier
     __device__ void release() const
     {
-        if (word) __hip_atomic_store(word, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!word) return;
+#if AZG_GATE_TIMED
+        const int held = (int)__builtin_amdgcn_s_memtime() - t_acq;
+        if (held > 0 && held < (1 << 20)) span = held;
+#endif
+        __hip_atomic_store(word, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 };
 
