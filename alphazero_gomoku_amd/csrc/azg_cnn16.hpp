@@ -261,6 +261,9 @@ __device__ inline void conv3x3_f16(const half8 *wp, WRing<RING, CW> &ring, const
     for (int c = 0; c < CW; c++) wrow[c] = conv_wrow<CINP>(wp, cg * CW + c, lane);
 #endif
     // dense phase: take issue priority over the co-resident workgroup's scalar / f64 tree code
+#if AZG_QUAD8 && AZG_QUAD_FINE
+    if (COUT >= 64) azg_simd_gate_acquire();
+#endif
     if (COUT >= 64) __builtin_amdgcn_s_setprio(2);
     if constexpr (BPF == 2) {
         // Activations one POSITION TILE ahead: the steps n = ks * PT + i form one sequence; the LDS
@@ -380,6 +383,9 @@ __device__ inline void conv3x3_f16(const half8 *wp, WRing<RING, CW> &ring, const
     }
     }
     if (COUT >= 64 && !KEEP_PRIO) __builtin_amdgcn_s_setprio(0);
+#if AZG_QUAD8 && AZG_QUAD_FINE
+    if (COUT >= 64) azg_simd_gate_release();
+#endif
     if (prof) prof->mark(slot);
     // prep() reads what every tile's epilogue needs from LDS once, before the first epilogue
     // store (the compiler must assume a later read could alias such a store and would
@@ -549,7 +555,7 @@ __device__ inline void conv3_wino_f16(const half8 *wp, const char *xh, const cha
         for (int q = 0; q < 4; q++) { mix(x0, q, false); mix(x0, q, true); }
         vstore(vbuf);
     }
-    __syncthreads();
+    azg_block_barrier();
     __builtin_amdgcn_s_setprio(AZG_WINO_PRIO);
     static_for<0, 16>([&](auto xi_c) {
         constexpr int xi = decltype(xi_c)::value;
@@ -592,7 +598,7 @@ __device__ inline void conv3_wino_f16(const half8 *wp, const char *xh, const cha
             __builtin_amdgcn_sched_barrier(0);
         }
         mprev = m;
-        __syncthreads();                 // V[xi + 1] is complete, V[xi] may be overwritten (after the last xi: by the epilogue)
+        azg_block_barrier();                 // V[xi + 1] is complete, V[xi] may be overwritten (after the last xi: by the epilogue)
     });
     yadd(std::integral_constant<int, 15>{}, 0);
     yadd(std::integral_constant<int, 15>{}, 1);
@@ -831,7 +837,7 @@ __device__ inline void cnn16_tail_sparse(const NetWeights &nw, float *lds, int t
     const int np = compact(4 * G::S, 0, lp);
     const int nv = compact(2 * G::S, 4, lv);
     if (lane == 0) { cnt[wave] = np; cnt[4 + wave] = nv; }
-    __syncthreads();
+    azg_block_barrier();
     prof.mark(7);
 
     // ---- act_fc1: this wave's inputs against all outputs, outputs 4*lane .. 4*lane+3 per lane
@@ -877,7 +883,7 @@ __device__ inline void cnn16_tail_sparse(const NetWeights &nw, float *lds, int t
         }
         *reinterpret_cast<f32x4 *>(lds + G::SPV_OFF + (wave * 4 + grp) * 64 + 4 * l16) = acc;
     }
-    __syncthreads();
+    azg_block_barrier();
     prof.mark(8);
 
     // ---- softmax over the S logits and the scalar value (wave 0; every partial is read before
@@ -917,7 +923,7 @@ __device__ inline void cnn16_tail_sparse(const NetWeights &nw, float *lds, int t
         const float v = wave_sum_f32(hdn * lb[G::B_WVFC2 + lane]);
         if (lane == 0) lds[G::VAL_OFF] = tanhf(v + lb[G::B_VFC2]);
     }
-    __syncthreads();
+    azg_block_barrier();
     prof.mark(9);
 }
 
@@ -1000,7 +1006,7 @@ __device__ inline void cnn16_tail(const NetWeights &nw, float *lds, int tid, Pro
         }
         }
     }
-    __syncthreads();
+    azg_block_barrier();
     prof.mark(7);
 
     // ---- act_fc1 and val_fc1
@@ -1019,7 +1025,7 @@ __device__ inline void cnn16_tail(const NetWeights &nw, float *lds, int tid, Pro
         fc16_run<G::T, 4, G::KWV>(wval, 4 * G::KWV, rval, xv, G::T * G::KPV * 2, n < G::T,
                                   part + G::OTP * 16 * G::T, kgrp, n);
     }
-    __syncthreads();
+    azg_block_barrier();
     prof.mark(8);
 
     // ---- softmax over the S logits and the scalar value, one wave per position
@@ -1060,7 +1066,7 @@ __device__ inline void cnn16_tail(const NetWeights &nw, float *lds, int tid, Pro
         v = wave_sum_f32(v);
         if (lane == 0) lds[G::VAL_OFF + leaf] = tanhf(v + lb[G::B_VFC2]);
     }
-    __syncthreads();
+    azg_block_barrier();
     prof.mark(9);
 }
 
@@ -1074,7 +1080,7 @@ __device__ inline void cnn16_forward(const NetWeights &nw_in, float *lds, InputF
     char *ldb = reinterpret_cast<char *>(lds);
     // The thread index is re-read opaquely on every call: per-lane addresses and masks derived
     // from it would otherwise be hoisted out of the caller's playout loop and held in registers.
-    int tid = threadIdx.x;
+    int tid = azg_tid();
     asm volatile("" : "+v"(tid));
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     __builtin_assume(wave >= 0 && wave < 4);               // 256-thread workgroups: lets tile-validity tests fold
@@ -1117,7 +1123,7 @@ __device__ inline void cnn16_forward(const NetWeights &nw_in, float *lds, InputF
         *reinterpret_cast<half8 *>(ldb + G::A1H_OFF + G::NP * G::RS_A1 + (tid - 64) * 16) = z8;
     if (tid >= 128 && tid < 128 + G::RS_A1 / 16)
         *reinterpret_cast<half8 *>(ldb + G::A1L_OFF + G::NP * G::RS_A1 + (tid - 128) * 16) = z8;
-    __syncthreads();
+    azg_block_barrier();
     prof.mark(2);
 
     // epilogue of conv1/conv2: scale back, bias, ReLU, split into halves, store [pos][channel]
@@ -1164,7 +1170,7 @@ __device__ inline void cnn16_forward(const NetWeights &nw_in, float *lds, InputF
     }
     prof.mark(16);
     if (tid == 0) gate.acquire();
-    __syncthreads();
+    azg_block_barrier();
     prof.mark(3);
     if constexpr (!kWino3) conv_preload<G, 64, 128, R3, CW3>(w3, wave, lane, ring3);
     conv3x3_f16<G, 32, 64, G::RS_A1, true, G::BPF, R2, CW2>(w2, ring2, ldb + G::A1H_OFF, ldb + G::A1L_OFF, wave, lane,
@@ -1172,7 +1178,7 @@ __device__ inline void cnn16_forward(const NetWeights &nw_in, float *lds, InputF
                                                store_split(ldb + G::A2H_OFF, ldb + G::A2L_OFF, G::RS_A2),
                                                &prof, 15);
     prof.mark(17);
-    __syncthreads();
+    azg_block_barrier();
     prof.mark(4);
 
     // ---- conv3; its output never goes to LDS: bias + ReLU in registers, split into halves,
@@ -1243,7 +1249,7 @@ __device__ inline void cnn16_forward(const NetWeights &nw_in, float *lds, InputF
                                                                    head_prep, head_epi, &prof);
     }
     prof.mark(5);
-    __syncthreads();
+    azg_block_barrier();
     if (tid == 0) gate.release();
     prof.mark(6);
     if constexpr (G::SPARSE_FC) cnn16_tail_sparse<G>(nw, lds, tid, prof);
@@ -1256,7 +1262,7 @@ __device__ inline void cnn16_prepare(const NetWeights &nw, float *lds)
 {
     char *ldb = reinterpret_cast<char *>(lds);
     const half8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
-    const int tid = threadIdx.x;
+    const int tid = azg_tid();
     if (tid < G::RS_A2 / 16) *reinterpret_cast<half8 *>(ldb + G::A2H_OFF + G::NP * G::RS_A2 + tid * 16) = z8;
     if (tid >= 64 && tid < 64 + G::RS_A2 / 16)
         *reinterpret_cast<half8 *>(ldb + G::A2L_OFF + G::NP * G::RS_A2 + (tid - 64) * 16) = z8;
@@ -1269,7 +1275,7 @@ __device__ inline void cnn16_prepare(const NetWeights &nw, float *lds)
     if (tid < 64) { lb[G::B_VFC1 + tid] = nw.bvfc1[tid]; lb[G::B_WVFC2 + tid] = nw.wvfc2[tid]; }
     if (tid == 64) lb[G::B_VFC2] = nw.bvfc2[0];
     for (int a = tid; a < G::S; a += 256) lb[G::B_PFC + a] = nw.bpfc[a];
-    __syncthreads();
+    azg_block_barrier();
 }
 
 }  // namespace azg

@@ -97,6 +97,68 @@ __device__ inline NetWeights opaque_weights(const NetWeights &w)
 // engines that run concurrently on separate streams pair up the same way.
 __device__ int g_matrix_gate[kGateWords];
 
+// Experiment builds (-DAZG_QUAD8=1, 8x8 only): ONE 512-thread workgroup per CU holds both game
+// pairs, as two groups of four waves that run the per-pair code independently on their own LDS
+// regions.  The hardware barrier would join all eight waves, so the groups use a barrier on two LDS
+// words each (arrival count, generation) at the start of the dynamic LDS, and the matrix gate is an
+// LDS word.  kLdsHead floats at the start of the dynamic LDS are reserved for these words.
+#ifndef AZG_QUAD8
+#define AZG_QUAD8 0
+#endif
+#if AZG_QUAD8
+constexpr int kLdsHead = 16;
+__device__ inline int azg_tid() { return (int)(threadIdx.x & 255u); }
+__device__ inline void azg_block_barrier()
+{
+    extern __shared__ unsigned azg_dyn_lds[];
+    unsigned *ctl = azg_dyn_lds + (threadIdx.x >> 8) * 4;          // [0] arrivals, [1] generation
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    const unsigned g0 = __hip_atomic_load(&ctl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if ((threadIdx.x & 63u) == 0) {
+        const unsigned old = atomicAdd(&ctl[0], 1u);
+        if (old == 3u) {
+            __hip_atomic_store(&ctl[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __hip_atomic_store(&ctl[1], g0 + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    }
+    for (int spin = 0; spin < (1 << 22); spin++) {
+        if (__hip_atomic_load(&ctl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != g0) break;
+        __builtin_amdgcn_s_sleep(0);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+#ifndef AZG_QUAD_FINE
+#define AZG_QUAD_FINE 0       // 1: the matrix gate per SIMD, held by a wave for the length of a k-loop only (measured 15 % slower)
+#endif
+// One gate word per SIMD (words 8..11 of the LDS head): wave w of either group runs on SIMD
+// HW_ID[5:4]; the two waves that share a SIMD take turns with their dense loops, nothing else waits.
+__device__ inline void azg_simd_gate_acquire()
+{
+    extern __shared__ unsigned azg_dyn_lds[];
+    unsigned *w = azg_dyn_lds + 8 + ((__builtin_amdgcn_s_getreg(4 | (4 << 6) | (1 << 11))) & 3u);
+    // Every lane issues the compare-and-swap (one instruction, the lanes are served one after the
+    // other: the first finds 0, the rest 1).  A branch for lane 0 alone, next to the unrolled MFMA
+    // loops with their scheduling directives, gave WRONG convolution results (measured: a lane-0
+    // store placed behind the k-loop is enough, the same store by all lanes is harmless).
+    for (int tries = 0; tries < 400000; tries++) {
+        const unsigned old = atomicCAS(w, 0u, 1u);
+        if (__ballot(old == 0u) != 0ULL) break;
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+__device__ inline void azg_simd_gate_release()
+{
+    extern __shared__ unsigned azg_dyn_lds[];
+    unsigned *w = azg_dyn_lds + 8 + ((__builtin_amdgcn_s_getreg(4 | (4 << 6) | (1 << 11))) & 3u);
+    __hip_atomic_store(w, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);      // all lanes, see acquire
+}
+#else
+constexpr int kLdsHead = 0;
+__device__ inline int azg_tid() { return (int)threadIdx.x; }
+__device__ inline void azg_block_barrier() { __syncthreads(); }
+#endif
+
 #ifndef AZG_GATE_TIMED
 #define AZG_GATE_TIMED 0      // 1: a waiting workgroup sleeps until the holder is due to release (see acquire)
 #endif
@@ -112,6 +174,10 @@ struct MatrixGate {
         const unsigned hw = __builtin_amdgcn_s_getreg(4 | (8 << 6) | (7 << 11));
         const unsigned xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11));
         word = enabled ? g_matrix_gate + ((xcc & 15u) * 256u + (hw & 255u)) : nullptr;
+#if AZG_QUAD8
+        extern __shared__ unsigned azg_dyn_lds[];
+        if (enabled) word = AZG_QUAD_FINE ? nullptr : reinterpret_cast<int *>(azg_dyn_lds + 12);      // both groups of the workgroup share it
+#endif
     }
     // thread 0 of the workgroup, followed by a workgroup barrier
     __device__ void acquire() const
@@ -136,9 +202,9 @@ struct MatrixGate {
             if (tries < 64) __builtin_amdgcn_s_sleep(1); else __builtin_amdgcn_s_sleep(16);
         }
 #else
-        for (int tries = 0; tries < 2000; tries++) {
+        for (int tries = 0; tries < (AZG_QUAD8 ? 200000 : 2000); tries++) {
             if (atomicCAS(word, 0, 1) == 0) return;
-            __builtin_amdgcn_s_sleep(16);
+            if (AZG_QUAD8) __builtin_amdgcn_s_sleep(1); else __builtin_amdgcn_s_sleep(16);
         }
 #endif
     }

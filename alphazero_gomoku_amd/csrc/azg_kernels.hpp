@@ -55,12 +55,23 @@ template <int N, int T, int MODE, bool F16>
 __device__ __forceinline__ void search_body(DevState st)
 {
     using G = typename GeomPick<(MODE == 0 ? N : 4), (MODE == 0 ? T : 1), F16>::type;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+    extern __shared__ __attribute__((aligned(16))) float smem_all[];
     using GL = GameLdsT<(MODE == 0 ? N * N + 1 : MAXS + 1)>;
+    // (experiment builds with two groups per workgroup: group `grp` owns its own region behind the
+    // reserved head of the dynamic LDS and the game pair 2 * blockIdx.x + grp)
+    constexpr bool kQuad = AZG_QUAD8 && F16 && MODE == 0;
+    constexpr int kRegion = (((MODE == 0 ? G::END : 0) * 4 + T * (int)sizeof(GL) + 255) / 256) * 64;      // floats
+    const int grp = kQuad ? (int)(threadIdx.x >> 8) : 0;
+    float *smem = smem_all + (kQuad ? kLdsHead + grp * kRegion : 0);
     GL *gls = reinterpret_cast<GL *>(smem + (MODE == 0 ? G::END : 0));
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    if (kQuad) {
+        // the barrier and gate words start at zero; the only hardware barrier of the kernel
+        if ((int)threadIdx.x < kLdsHead) reinterpret_cast<unsigned *>(smem_all)[threadIdx.x] = 0u;
+        __syncthreads();
+    }
+    const int tid = kQuad ? azg_tid() : (int)threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const bool tree_wave = wave < T;
-    const int g = blockIdx.x * T + wave;
+    const int g = (kQuad ? 2 * blockIdx.x + grp : blockIdx.x) * T + wave;
     GL *gl = &gls[tree_wave ? wave : 0];
 
     if (tree_wave) {
@@ -78,7 +89,7 @@ __device__ __forceinline__ void search_body(DevState st)
             }
         }
     }
-    __syncthreads();
+    if (kQuad) azg_block_barrier(); else __syncthreads();
     bool any_live = false;
 #pragma unroll
     for (int t = 0; t < T; t++) any_live |= gls[t].live != 0;
@@ -118,7 +129,7 @@ __device__ __forceinline__ void search_body(DevState st)
         }
         prof.mark(0);
         if (MODE == 0) {
-            __syncthreads();
+            if (kQuad) azg_block_barrier(); else __syncthreads();
             prof.mark(1);
             bool any = false;
 #pragma unroll
@@ -129,7 +140,7 @@ __device__ __forceinline__ void search_body(DevState st)
                     planes_at(q->leaf_bb, N, q->leaf_ply, q->leaf_last, q->first_player, q->live != 0, row, col, out);
                 }, prof, gate);
             } else {
-                __syncthreads();
+                if (kQuad) azg_block_barrier(); else __syncthreads();
             }
         }
         if (active) {
@@ -212,6 +223,10 @@ AZG_CAPPED_SEARCH_KERNEL(search_kernel_f16_7x7, 7, 2)
 AZG_CAPPED_SEARCH_KERNEL(search_kernel_f16_8x8, 8, 2)
 #endif
 #endif
+#if AZG_QUAD8
+// experiment: both game pairs of a CU in one workgroup (see azg_device.hpp)
+__global__ __launch_bounds__(512, 1) void search_quad_kernel_8x8(DevState st) { search_body<8, 2, 0, true>(st); }
+#endif
 
 // ---------------------------------------------------------------- one playout, evaluated by the host
 // MCTS._playout (mcts_alphaZero.py:113-148) split at the policy call (:132), for a caller whose
@@ -277,7 +292,12 @@ __global__ __launch_bounds__(256) void eval_kernel(NetWeights nw, const float *s
                                                    float *probs, float *values, int *bad)
 {
     using G = typename GeomPick<N, T, F16>::type;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+    extern __shared__ __attribute__((aligned(16))) float smem_all[];
+    float *smem = smem_all + ((AZG_QUAD8 && F16) ? kLdsHead : 0);
+    if (AZG_QUAD8 && F16) {
+        if ((int)threadIdx.x < kLdsHead) reinterpret_cast<unsigned *>(smem_all)[threadIdx.x] = 0u;
+        __syncthreads();
+    }
     const int n0 = blockIdx.x * T;
     net_prepare<G, F16>(nw, smem);
     Prof prof;

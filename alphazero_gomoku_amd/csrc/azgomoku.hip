@@ -266,7 +266,13 @@ static bool pick_search(int N, int mode, int cnn_mode, SearchLaunch *out)
 #ifdef AZG_ONLY8                 // experiment builds: the 8x8 split-f16 kernels only (compiles in a third of the time)
     if (N != 8 || !f16) return false;
     *out = net_launch<8, AZG_T8, true>();
-#if AZG_OCC8 == 2 && AZG_T8 == 2
+#if AZG_QUAD8
+    {
+        using G = typename GeomPick<8, 2, true>::type;
+        const size_t region = (((size_t)G::END * 4 + 2 * sizeof(GameLdsT<65>) + 255) / 256) * 256;     // bytes, as in search_body
+        *out = {search_quad_kernel_8x8, 4, (size_t)kLdsHead * 4 + 2 * region, 512};
+    }
+#elif AZG_OCC8 == 2 && AZG_T8 == 2
     out->fn = search_kernel_f16_8x8;
 #endif
     return true;
@@ -310,7 +316,7 @@ template <int N, int T, bool F16>
 static EvalLaunch eval_launch()
 {
     using G = typename GeomPick<N, T, F16>::type;
-    return {eval_kernel<N, T, F16>, T, (size_t)G::END * 4};
+    return {eval_kernel<N, T, F16>, T, (size_t)G::END * 4 + (F16 ? (size_t)kLdsHead * 4 : 0)};
 }
 
 static bool pick_eval(int N, int cnn_mode, EvalLaunch *out)
