@@ -527,7 +527,7 @@ __device__ inline void wave_fit_arena(const DevState &st, int g, int ply, int la
     if (st.big_of[g] >= 0 || (long long)used + (long long)st.n_playout * (st.S - ply) <= (long long)st.cap) return;
     int slot = -1;
     if (lane == 0) {
-        for (int p = 0; p < st.n_big; p++)
+        for (int i = 0, p = g % max(st.n_big, 1); i < st.n_big; i++, p = p + 1 == st.n_big ? 0 : p + 1)
             if (atomicCAS(&st.big_owner[p], -1, g) == -1) { slot = p; break; }
     }
     slot = __shfl(slot, 0);

@@ -484,9 +484,11 @@ static int create_impl(azg_handle *h)
     if ((rc = dev_alloc(h, &st.eChild, E, false))) return rc;
     if ((rc = dev_alloc(h, &st.eMeta, E, false))) return rc;
     if ((rc = dev_alloc(h, &st.used, B))) return rc;
-    // large arenas (see DevState): as many as asked for, by default 16, within 16 GB
+    // large arenas (see DevState): as many as asked for; by default one per four game slots (a net
+    // with peaked priors keeps most of its tree from move to move, and a game holds its large arena
+    // until it ends), at least 16, within 16 GB
     st.cap_big = 2 + c.n_playout * ((S + 1) / 2) * ((S + 1) / 2);
-    st.n_big = c.big_arenas < 0 ? 0 : std::min(B, c.big_arenas > 0 ? c.big_arenas : 16);
+    st.n_big = c.big_arenas < 0 ? 0 : std::min(B, c.big_arenas > 0 ? c.big_arenas : std::max(16, B / 4));
     if (c.big_arenas <= 0)
         while (st.n_big > 0 && (size_t)st.n_big * 2 * st.cap_big * 24 > ((size_t)16 << 30)) st.n_big--;
     if (st.cap_big <= st.cap) st.n_big = 0;                  // the standard arenas already hold any tree

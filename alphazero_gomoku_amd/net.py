@@ -115,6 +115,19 @@ class PolicyValueNet(object):
             sd[k].copy_(torch.from_numpy(np.array(p, dtype=np.float32, order="C", copy=True)).reshape(sd[k].shape))
         self.version += 1
 
+    def zero_head_biases(self):
+        """Set the biases of the two 1x1 head convolutions (4 policy channels, 2 value channels) to
+        zero.  A freshly initialised trunk puts out |a3| of about 0.02 while PyTorch draws these
+        biases from U(-0.088, 0.088), so at the start every head channel is switched on or off for
+        ALL positions by the sign of its bias alone: one net in four starts with both value channels
+        dead, and a few large early optimiser steps can push the remaining ones under as well, after
+        which the heads pass no gradient and the net never learns.  With zero biases the sign follows
+        the position and about half of every channel is active."""
+        with torch.no_grad():
+            self.policy_value_net.act_conv1.bias.zero_()
+            self.policy_value_net.val_conv1.bias.zero_()
+        self.version += 1
+
     def load_model(self, model_file, layout=None):
         """A PyTorch state_dict file (what save_model and the reference's PyTorch net write,
         policy_value_net_pytorch.py:150-157), an .npz archive of the 16 parameter arrays

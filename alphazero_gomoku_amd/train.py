@@ -44,15 +44,22 @@ class TrainPipeline:
                       that matters; with mini-batches drawn from hundreds of thousands of fresh tuples KL
                       stays below kl_targ/2 until learn_rate x 11.39 = 0.023 wrecks the net (measured: every
                       ReLU dead after seven updates, loss stuck at 5.15; a ceiling of 4, i.e. up to 5.06,
-                      still ends that way; 2, i.e. up to 2.25, learns: loss 5.14 -> 2.45 and 9 of 10 games
-                      won against the 1000-playout rollout player after 24 batches of 1024 games with 48
-                      updates each).  Default (None): 10 with play_batch_size 1, else 2."""
+                      still ends that way; with 2, i.e. up to 2.25, the net of three runs in six was dead
+                      within its first dozen updates and stayed so: KL = 0 and loss 5.16 for good; with 1
+                      only a net that STARTED with a dead value head failed, see zero_head_biases).
+                      Default (None): 10 with play_batch_size 1, else 1 (the multiplier starts at 1 and
+                      can then only fall: the learning rate never exceeds learn_rate).
+    zero_head_biases  a net created here (no init_model, no policy_value_net) gets the biases of its two
+                      1x1 head convolutions zeroed (PolicyValueNet.zero_head_biases says why).  Default
+                      (None): only when games are played in batches, where dozens of updates at the full
+                      learning rate follow each other on a net that has not moved yet; with this and the
+                      ceiling of 1, twenty of twenty differently seeded runs learned."""
 
     def __init__(self, board_width=8, board_height=8, n_in_row=5, init_model=None, learn_rate=2e-3,
                  lr_multiplier=1.0, temp=1.0, n_playout=400, c_puct=5, buffer_size=10000, batch_size=512,
                  play_batch_size=1, epochs=5, kl_targ=0.02, check_freq=50, game_batch_num=1500,
                  n_parallel=1024, device=0, seed0=0, policy_value_net=None, pure_mcts_playout_num=1000,
-                 updates_per_batch=1, continuous=False, rng=None, max_lr_multiplier=None):
+                 updates_per_batch=1, continuous=False, rng=None, max_lr_multiplier=None, zero_head_biases=None):
         import torch
         from .net import PolicyValueNet
         self.board_width, self.board_height, self.n_in_row = board_width, board_height, n_in_row
@@ -66,11 +73,14 @@ class TrainPipeline:
         self.play_batch_size, self.epochs, self.kl_targ = play_batch_size, epochs, kl_targ
         self.check_freq, self.game_batch_num = check_freq, game_batch_num
         self.updates_per_batch, self.continuous = int(updates_per_batch), bool(continuous)
-        self.max_lr_multiplier = float(max_lr_multiplier) if max_lr_multiplier is not None else (10.0 if play_batch_size <= 1 else 2.0)
+        self.max_lr_multiplier = float(max_lr_multiplier) if max_lr_multiplier is not None else (10.0 if play_batch_size <= 1 else 1.0)
         self.best_win_ratio = 0.2                                            # train.py:88
         self.pure_mcts_playout_num = pure_mcts_playout_num
+        fresh = policy_value_net is None and not init_model
         self.policy_value_net = policy_value_net or PolicyValueNet(board_width, board_height, model_file=init_model,
                                                                    device=device)
+        if fresh and (play_batch_size > 1 if zero_head_biases is None else zero_head_biases):
+            self.policy_value_net.zero_head_biases()
         self.device, self.seed0, self.games_played = device, seed0, 0
         self.rank, self.world = 0, 1
         try:
@@ -250,10 +260,13 @@ class TrainPipeline:
         return 1.0 * (win_cnt[1] + 0.5 * win_cnt[-1]) / n_games
 
     # ---- train.py:278-340 --------------------------------------------------------------------
-    def run(self, on_batch=None, best_model=None, evaluate_games=10):
+    def run(self, on_batch=None, best_model=None, evaluate_games=10, evaluate_batched=False):
         """Self-play -> policy update, and every check_freq batches an evaluation against the rollout
         player: a new best win ratio saves the model to best_model (when given); a perfect score
-        strengthens the opponent by 1000 playouts and resets the mark (train.py:324-338)."""
+        strengthens the opponent by 1000 playouts and resets the mark (train.py:324-338).
+        evaluate_batched plays the evaluation games side by side (policy_evaluate(batched=True));
+        every evaluation is appended to self.eval_history as (batch, rollout playouts, win ratio)."""
+        self.eval_history = []
         for i in range(self.game_batch_num):
             self.collect_selfplay_data(self.play_batch_size)
             loss = entropy = None
@@ -278,7 +291,8 @@ class TrainPipeline:
                 on_batch(i, self.episode_len, loss, entropy)
             if self.check_freq and (i + 1) % self.check_freq == 0 and evaluate_games > 0:
                 if self.rank == 0:
-                    win_ratio = self.policy_evaluate(evaluate_games)
+                    win_ratio = self.policy_evaluate(evaluate_games, batched=evaluate_batched, seed0=1000 * (i + 1))
+                    self.eval_history.append((i + 1, self.pure_mcts_playout_num, win_ratio))
                     if win_ratio > self.best_win_ratio:
                         self.best_win_ratio = win_ratio
                         if best_model:
@@ -303,6 +317,7 @@ def main(argv=None):
     import argparse
     import json
     import os
+    import sys
     import time
     ap = argparse.ArgumentParser(description=main.__doc__)
     ap.add_argument("--board", type=int, default=8)
@@ -325,11 +340,13 @@ def main(argv=None):
     ap.add_argument("--slots", type=int, default=1024, help="game slots per GPU")
     ap.add_argument("--final-eval", type=int, default=0,
                     help="after the loop, play this many games against the rollout player (batched arena) and report the win ratio")
+    ap.add_argument("--eval-games", type=int, default=10, help="games per evaluation of --check-freq")
+    ap.add_argument("--eval-batched", action="store_true", help="play the evaluation games side by side on the GPU")
     ap.add_argument("--lr-multiplier", type=float, default=1.0, help="start value of the adaptive learning-rate multiplier")
     ap.add_argument("--max-lr-multiplier", type=float, default=None,
                     help="the KL controller raises the multiplier only below this (the reference's rule is 10, which "
                          "lets the learning rate reach 0.023: too much for mini-batches of fresh tuples from 1024 games; "
-                         "default 2, or 10 with --play-batch 1)")
+                         "default 1, or 10 with --play-batch 1)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="every rank uses GPU 0 and the collectives go over gloo: runs the multi-rank code path on a "
                          "one-GPU machine (RCCL refuses two ranks on one device); not a measurement")
@@ -378,7 +395,12 @@ def main(argv=None):
         dist.barrier()
     log = []
     t0 = time.perf_counter()
-    tp.run(on_batch=lambda i, n, loss, ent: log.append((i, n, loss, ent)))
+    def on_batch(i, n_samples, loss, ent):
+        log.append((i, n_samples, loss, ent))
+        if rank == 0 and (i + 1) % 8 == 0:                 # a sign of life for whoever watches a long run
+            print("batch %d: %d games, loss %s, %.0f s" % (i + 1, tp.games_played, "%.3f" % loss if loss is not None else "-",
+                                                         time.perf_counter() - t0), file=sys.stderr, flush=True)
+    tp.run(on_batch=on_batch, evaluate_games=args.eval_games, evaluate_batched=args.eval_batched)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     final = None
@@ -400,6 +422,7 @@ def main(argv=None):
                           "entropy_first_last": [tp.loss_history[0][1], tp.loss_history[-1][1]] if tp.loss_history else None,
                           "win_ratio_vs_rollout_player": final, "rollout_playouts": tp.pure_mcts_playout_num,
                           "lr_multiplier": tp.lr_multiplier, "max_lr_multiplier": tp.max_lr_multiplier, "best_win_ratio": tp.best_win_ratio,
+                          "evaluations_batch_playouts_win_ratio": tp.eval_history,
                           "timer": "starts after one optimiser step on a scratch net (library initialisation), ends after the last update"}))
     if world > 1:
         dist.destroy_process_group()

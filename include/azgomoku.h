@@ -63,7 +63,8 @@ typedef struct azg_config {
     int32_t arena_nodes;   /* expanded nodes kept per game tree; 0 = 4*n_playout+64   */
     int32_t cnn_mode;      /* AZG_CNN_*                                               */
     int32_t big_arenas;    /* large tree arenas shared by the games whose re-used tree outgrows
-                              arena_nodes; 0 = 16 (fewer if they would exceed 16 GB), < 0 = none */
+                              arena_nodes; 0 = max(16, n_games / 4), at most n_games (fewer if they
+                              would exceed 16 GB), < 0 = none */
 } azg_config;
 
 /* MCTSPlayer.__init__ / MCTS.__init__ (mcts_alphaZero.py:98-111,201-203) plus

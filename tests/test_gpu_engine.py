@@ -684,6 +684,29 @@ def test_policy_evaluate_runs(az):
     assert 0.0 <= ratio <= 1.0 and sum(tp.last_win_cnt.values()) == 2
 
 
+def test_run_evaluates_every_check_freq_batches_and_strengthens_the_opponent(az, monkeypatch):
+    """TrainPipeline.run (train.py:328-344): every check_freq batches the current net plays the
+    rollout player; a win ratio above the best so far becomes the mark (and saves the model), a
+    perfect score adds 1000 playouts to the opponent and resets the mark to 0."""
+    from alphazero_gomoku_amd.train import TrainPipeline
+    tp = TrainPipeline(board_width=6, board_height=6, n_in_row=4, n_playout=16, play_batch_size=4, batch_size=16,
+                       buffer_size=400, epochs=1, game_batch_num=4, n_parallel=4, check_freq=2, pure_mcts_playout_num=20)
+    tp.run(evaluate_games=2, evaluate_batched=True)           # real games, side by side
+    assert [e[0] for e in tp.eval_history] == [2, 4] and all(0.0 <= e[2] <= 1.0 for e in tp.eval_history)
+    assert sum(tp.last_win_cnt.values()) == 2
+    # the gating rule on scripted win ratios
+    tp2 = TrainPipeline(board_width=6, board_height=6, n_in_row=4, n_playout=16, play_batch_size=4, batch_size=16,
+                        buffer_size=400, epochs=1, game_batch_num=5, n_parallel=4, check_freq=1, pure_mcts_playout_num=4000)
+    script = iter([0.1, 0.6, 1.0, 1.0, 0.3])
+    monkeypatch.setattr(tp2, "policy_evaluate", lambda n, batched=False, seed0=0: next(script))
+    saved = []
+    monkeypatch.setattr(tp2.policy_value_net, "save_model", lambda path: saved.append((path, tp2.best_win_ratio)))
+    tp2.run(best_model="best.model", evaluate_games=2)
+    assert [e[1:] for e in tp2.eval_history] == [(4000, 0.1), (4000, 0.6), (4000, 1.0), (5000, 1.0), (5000, 0.3)]
+    assert saved == [("best.model", 0.6), ("best.model", 1.0), ("best.model", 1.0)]   # 0.1 is below the 0.2 start mark
+    assert tp2.pure_mcts_playout_num == 5000 and tp2.best_win_ratio == 1.0            # 5000 is the ceiling: no reset there
+
+
 def test_batched_arena_equals_seeded_dropin_games(az):
     """arena.play_arena_games: game i of the batch is the game the drop-in players produce after
     np.random.seed(seed0 + i); random.seed(seed0 + i), with start_player = i % 2."""

@@ -303,21 +303,25 @@ def test_batched_training_loop_learns(az):
     """The loop as a whole must LEARN when games are played in batches.  (At 8x8 with 1024 games per
     batch the reference's controller, train.py:196-200, raised the learning rate to 0.023 while the KL
     of mini-batches of fresh tuples stayed small; after seven updates every ReLU of the net was dead
-    and the loss sat at 1.0 + log(S).  The pipeline therefore stops raising the multiplier at 2 when
-    play_batch_size > 1.)  Here, small: the ceiling is the batched one, the loss falls, and the net
-    still tells positions apart."""
+    and the loss sat at 1.0 + log(S); and a net whose 1x1 head convolutions start switched off by their
+    biases cannot learn at all.  The pipeline therefore never raises the multiplier above 1 when
+    play_batch_size > 1 and starts a net of its own with zero head biases.)  Here, small: both
+    measures are in force, the loss falls, and the net still tells positions apart."""
     import torch
     from alphazero_gomoku_amd.train import TrainPipeline
     torch.manual_seed(0)
     tp = TrainPipeline(board_width=6, board_height=6, n_in_row=4, n_playout=48, play_batch_size=256, n_parallel=256,
                        batch_size=256, buffer_size=60000, game_batch_num=6, updates_per_batch=24, check_freq=0)
-    assert tp.max_lr_multiplier == 2.0
+    assert tp.max_lr_multiplier == 1.0
+    net = tp.policy_value_net.policy_value_net
+    assert float(net.act_conv1.bias.abs().max()) == 0.0 and float(net.val_conv1.bias.abs().max()) == 0.0
+    assert float(net.conv3.bias.abs().max()) > 0.0                           # only the head convolutions
     tp.run()
     h = tp.loss_history
     assert len(h) == 5 * 24 or len(h) == 6 * 24
     first, last = np.mean([l for l, _ in h[:8]]), np.mean([l for l, _ in h[-8:]])
     assert last < first - 0.3, (first, last)
-    assert tp.lr_multiplier <= 2.25
+    assert tp.lr_multiplier <= 1.0
     s, p, z = tp.data_buffer.take(tp.data_buffer.draw(256))
     probs, v = tp.policy_value_net.policy_value(s)
     assert float(probs.std(0).mean()) > 1e-3 and float(v.std()) > 1e-2      # not a constant function

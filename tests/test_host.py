@@ -270,7 +270,7 @@ def test_policy_update_schedule_matches_reference():
 
 def test_lr_multiplier_ceiling():
     """The multiplier rises (x1.5) only while below max_lr_multiplier: 10 in the reference (so it can
-    reach 11.39), 2 by default when games are played in batches (so it stops at 2.25)."""
+    reach 11.39), 1 by default when games are played in batches (it starts at 1 and can only fall)."""
     import random
     from alphazero_gomoku_amd.train import TrainPipeline
     from alphazero_gomoku_amd.train_data import ReplayBuffer
