@@ -285,6 +285,7 @@ struct DevState {
     unsigned long long *arena_stats;   // [2] moves into a large arena | trees dropped because none was free
     unsigned char *cur;            // [B]
     int rr_cap;                    // LDS entries of a re-root's work stack (128 .. kRerootStackMax)
+    int rr_always;                 // 1: every re-root compacts the kept subtree into the other arena (tests)
     long long *evals;              // [B] leaf evaluations that needed priors (profiling)
     // per-game training samples, two banks per slot: the game in progress records into bank
     // s_bank[g]; a slot restarted on the device (pipelined self-play) flips the bank, so the

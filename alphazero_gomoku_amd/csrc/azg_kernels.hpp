@@ -544,6 +544,28 @@ __device__ inline void wave_fit_arena(const DevState &st, int g, int ply, int la
     if (lane == 0) { st.big_of[g] = slot; atomicAdd(&st.arena_stats[0], 1ULL); }
 }
 
+// MCTS.update_with_move (mcts_alphaZero.py:183-192) as the callers use it: child edge `c` becomes the
+// root.  While the arena has room for another search behind everything it holds, that is five stores:
+// the child's record goes to edge 0 of the SAME arena and the blocks below it stay where they are
+// (the siblings' subtrees and the old root's block become garbage; edge indices are unchanged, so
+// the tree the next search sees is the tree a copy would have made).  Only when
+// used + n_playout * (S - ply) no longer fits is the kept subtree compacted into the other arena
+// (wave_reroot), and if even the compacted tree may outgrow the arena it moves to a large one
+// (wave_fit_arena).  ply: plies on the board the next search starts from.
+__device__ inline void wave_update_with_move(const DevState &st, int g, int c, int ply, int lane, int *rr)
+{
+    const long long need = (long long)st.n_playout * (st.S - ply);
+    if (st.rr_always || (long long)st.used[g] + need > (long long)arena_cap(st, g)) {
+        wave_reroot(st, g, c, lane, rr, st.rr_cap);
+    } else if (lane == 0) {
+        const TreeView t = tree_view(st, g, st.cur[g]);
+        const float p = t.P[c]; const int nv = t.N[c]; const double q = t.Q[c];
+        const int ch = t.child[c]; const unsigned m = t.meta[c];
+        t.P[0] = p; t.N[0] = nv; t.Q[0] = q; t.child[0] = ch; t.meta[0] = m;
+    }
+    wave_fit_arena(st, g, ply, lane);
+}
+
 // MCTSPlayer.get_action's tail (mcts_alphaZero.py:216-242) + Game.start_self_play's
 // bookkeeping (game.py:381-391) for one game per wave.  noise: [B][S] Dirichlet draws
 // in child order, u01: [B] uniforms (both from the game's numpy-legacy stream).
@@ -675,8 +697,7 @@ __global__ __launch_bounds__(256) void advance_kernel(DevState st, double temp, 
         if (ended || child_idx < 0) {
             if (lane == 0) fresh_root(st, g, st.cur[g]);      // reset_player / unknown move
         } else {
-            wave_reroot(st, g, base + child_idx, lane, s_rr[wave], st.rr_cap);
-            wave_fit_arena(st, g, (flags & ADV_BOARD) ? ply + 1 : ply, lane);
+            wave_update_with_move(st, g, base + child_idx, (flags & ADV_BOARD) ? ply + 1 : ply, lane, s_rr[wave]);
         }
     }
     if ((flags & ADV_RESTART) && ended) {
@@ -726,8 +747,7 @@ __global__ __launch_bounds__(256) void reroot_kernel(DevState st, const int *mov
         }
     if (child_idx < 0) { if (lane == 0) fresh_root(st, g, st.cur[g]); }
     else {
-        wave_reroot(st, g, base + child_idx, lane, s_rr[wave], st.rr_cap);
-        wave_fit_arena(st, g, st.ply[g], lane);
+        wave_update_with_move(st, g, base + child_idx, st.ply[g], lane, s_rr[wave]);
     }
 }
 

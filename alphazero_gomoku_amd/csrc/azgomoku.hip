@@ -457,6 +457,26 @@ static int create_impl(azg_handle *h)
         const char *e = getenv("AZG_REROOT_STACK");
         const int want = e ? atoi(e) : kRerootStackMax;
         st.rr_cap = want < 128 ? 128 : (want > kRerootStackMax ? kRerootStackMax : want);
+        // AZG_REROOT_COPY=1: every re-root copies the kept subtree (otherwise only when the arena runs low)
+        const char *a = getenv("AZG_REROOT_COPY");
+        st.rr_always = a && atoi(a) != 0;
+    }
+    if (h->cfg.arena_nodes == 0) {
+        // Default arena: room for the trees of 16 searches (8, 4 when memory is short).  A re-root
+        // leaves the kept subtree where it is while the arena has room for the next search behind
+        // it, so a roomy arena means a game compacts its tree once in many moves instead of copying
+        // it every move; the five arrays of all games stay within 64 GB and a quarter of the free memory.
+        size_t free_b = 0, total_b = 0;
+        HIPCHK(h, hipMemGetInfo(&free_b, &total_b));
+        const size_t budget = std::min<size_t>((size_t)64 << 30, free_b / 4);
+        int mult = 16;
+        while (mult > 4 && (size_t)B * 2 * (1 + ((size_t)mult * c.n_playout + 64) * S) * 24 > budget) mult /= 2;
+        h->cfg.arena_nodes = mult * c.n_playout + 64;
+        // within a tenth of the size that holds ANY tree of the configuration: take that size, and
+        // the shared large arenas below are not needed at all
+        const long long any = 2 + (long long)c.n_playout * ((S + 1) / 2) * ((S + 1) / 2);
+        if ((1 + (long long)h->cfg.arena_nodes * S) * 10 >= any * 9)
+            h->cfg.arena_nodes = (int)((any + S - 1) / S);
     }
     st.cap = 1 + h->cfg.arena_nodes * S;
     const size_t E = (size_t)B * 2 * st.cap;
@@ -558,7 +578,7 @@ extern "C" int azg_create(const azg_config *cfg, azg_handle **out)
     if (cfg->device < 0 || cfg->device >= ndev) return fail(nullptr, AZG_EINVAL, "device %d out of range (%d devices)", cfg->device, ndev);
     azg_handle *h = new azg_handle();
     h->cfg = *cfg;
-    if (h->cfg.arena_nodes <= 0) h->cfg.arena_nodes = 4 * cfg->n_playout + 64;
+    if (h->cfg.arena_nodes <= 0) h->cfg.arena_nodes = 0;      // chosen in create_impl, with the device current
     int rc = create_impl(h);
     if (rc != AZG_OK) {
         g_create_error = h->err;

@@ -183,6 +183,8 @@ def main():
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="every rank uses GPU 0 and the exchange goes over gloo: runs the sharded code path with several "
                          "processes on a one-GPU machine (RCCL refuses two ranks on one device); NOT a benchmark")
+    ap.add_argument("--arena-nodes", type=int, default=0,
+                    help="expanded nodes a game's tree arena holds (0 = the library's default, 16 searches' worth when memory allows)")
     ap.add_argument("--cnn", choices=["f16x3", "f32"], default="f16x3",
                     help="conv arithmetic: split-f16 MFMA (three products, f32 accumulate) or f32-input MFMA")
     args = ap.parse_args()
@@ -222,7 +224,7 @@ def main():
 
     n, k = args.board, args.n_in_row
     params = random_init_params(n, dev)
-    eng = az.SelfPlayEngine(n, k, args.playouts, args.games, 5.0, device=local_rank,
+    eng = az.SelfPlayEngine(n, k, args.playouts, args.games, 5.0, device=local_rank, arena_nodes=args.arena_nodes,
                             cnn_mode=az._lib.CNN_F16X3 if args.cnn == "f16x3" else az._lib.CNN_F32)
     eng.set_weights(params)
     drained = []

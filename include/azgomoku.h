@@ -60,7 +60,8 @@ typedef struct azg_config {
     double  c_puct;        /* mcts_alphaZero.py:98                                    */
     int32_t device;        /* HIP device ordinal                                      */
     int32_t prior_mode;    /* AZG_PRIOR_*                                             */
-    int32_t arena_nodes;   /* expanded nodes kept per game tree; 0 = 4*n_playout+64   */
+    int32_t arena_nodes;   /* expanded nodes an arena holds per game; 0 = 16*n_playout+64
+                              (8x, 4x when all arenas would exceed 64 GB or a quarter of the free memory) */
     int32_t cnn_mode;      /* AZG_CNN_*                                               */
     int32_t big_arenas;    /* large tree arenas shared by the games whose re-used tree outgrows
                               arena_nodes; 0 = max(16, n_games / 4), at most n_games (fewer if they

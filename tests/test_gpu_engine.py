@@ -313,8 +313,10 @@ def test_reroot_with_a_small_work_stack(az, oracle, n, k, npo, monkeypatch):
     nearly every move; the kept statistics must still equal the oracle's, visit for visit, Q for Q --
     on 15x15 with child blocks wider than a wave."""
     monkeypatch.setenv("AZG_REROOT_STACK", "128")
+    monkeypatch.setenv("AZG_REROOT_COPY", "1")        # copy on every move, not only when the arena runs low
     eng = az.SelfPlayEngine(n, k, npo, 2, prior_mode=az.PRIOR_HASH)
     monkeypatch.delenv("AZG_REROOT_STACK")
+    monkeypatch.delenv("AZG_REROOT_COPY")
     eng.reset_games()
     plies = _forced_line(az, oracle, eng, "hash", n, k, npo, 10, (0, 1))
     assert plies >= 5
