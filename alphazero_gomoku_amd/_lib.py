@@ -20,7 +20,7 @@ SYMBOLS = ["azg_create", "azg_destroy", "azg_last_error", "azg_set_weights", "az
            "azg_advance", "azg_update_with_move", "azg_status", "azg_states",
            "azg_drain_samples", "azg_eval_batch", "azg_board_step_batch", "azg_profile",
            "azg_stream", "azg_selfplay_begin", "azg_selfplay_step", "azg_selfplay_fetch",
-           "azg_selfplay_end", "azg_equi_data", "azg_pure_search", "azg_host_timing", "azg_arena_stats", "azg_selfplay_fetch_packed", "azg_unpack_states", "azg_playout_begin", "azg_playout_end",
+           "azg_selfplay_end", "azg_equi_data", "azg_pure_search", "azg_host_timing", "azg_arena_stats", "azg_reroot_stats", "azg_selfplay_fetch_packed", "azg_unpack_states", "azg_playout_begin", "azg_playout_end",
            "azg_board_step_batch_static"]
 
 
@@ -108,6 +108,7 @@ def load():
     L.azg_board_step_batch_static.argtypes = [vp, C.c_int, u64p, i32p, i32p, i32p, i32p, u8p, i8p, f32p]
     L.azg_host_timing.argtypes = [vp, f64p, i64p]
     L.azg_arena_stats.argtypes = [vp, i64p, i64p]
+    L.azg_reroot_stats.argtypes = [vp, i64p, i64p]
     L.azg_pure_search.argtypes = [vp, C.c_int, C.POINTER(C.c_uint32), i32p]
     L.azg_profile.argtypes = [vp, i64p, f64p, i64p]
     L.azg_stream.argtypes = [vp]

@@ -282,7 +282,7 @@ struct DevState {
     int *big_of;                   // [B] large arena the game lives in, or -1
     int *big_owner;                // [n_big] slot that owns the large arena, or -1
     float *bP; int *bN; double *bQ; int *bChild; unsigned *bMeta;   // [n_big][2][cap_big]
-    unsigned long long *arena_stats;   // [2] moves into a large arena | trees dropped because none was free
+    unsigned long long *arena_stats;   // [4] moves into a large arena | trees dropped because none was free | re-roots in place | re-roots that compacted
     unsigned char *cur;            // [B]
     int rr_cap;                    // LDS entries of a re-root's work stack (128 .. kRerootStackMax)
     int rr_always;                 // 1: every re-root compacts the kept subtree into the other arena (tests)

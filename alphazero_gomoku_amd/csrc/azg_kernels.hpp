@@ -557,7 +557,9 @@ __device__ inline void wave_update_with_move(const DevState &st, int g, int c, i
     const long long need = (long long)st.n_playout * (st.S - ply);
     if (st.rr_always || (long long)st.used[g] + need > (long long)arena_cap(st, g)) {
         wave_reroot(st, g, c, lane, rr, st.rr_cap);
+        if (lane == 0) atomicAdd(&st.arena_stats[3], 1ULL);
     } else if (lane == 0) {
+        atomicAdd(&st.arena_stats[2], 1ULL);
         const TreeView t = tree_view(st, g, st.cur[g]);
         const float p = t.P[c]; const int nv = t.N[c]; const double q = t.Q[c];
         const int ch = t.child[c]; const unsigned m = t.meta[c];

@@ -447,7 +447,7 @@ static int create_impl(azg_handle *h)
     HIPCHK(h, hipSetDevice(c.device));
     HIPCHK(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     HIPCHK(h, static_scratch_ptr(c.device, &h->static_scratch));
-    HIPCHK(h, hipHostMalloc((void **)&h->h_static_bad, 64));   // [0] board-step flag, bytes 16..31 arena counters, [12] CNN range flag
+    HIPCHK(h, hipHostMalloc((void **)&h->h_static_bad, 64));   // [0] board-step flag, bytes 16..47 arena and re-root counters, [12] CNN range flag
     DevState &st = h->st;
     st.N = N; st.S = S; st.NW = (S + 63) / 64; st.n_in_row = c.n_in_row; st.B = B;
     st.prior_mode = c.prior_mode; st.n_playout = c.n_playout; st.c_puct = c.c_puct;
@@ -522,7 +522,7 @@ static int create_impl(azg_handle *h)
     if ((rc = dev_alloc(h, &st.bQ, EB, false))) return rc;
     if ((rc = dev_alloc(h, &st.bChild, EB, false))) return rc;
     if ((rc = dev_alloc(h, &st.bMeta, EB, false))) return rc;
-    if ((rc = dev_alloc(h, &st.arena_stats, 2))) return rc;
+    if ((rc = dev_alloc(h, &st.arena_stats, 4))) return rc;
     if ((rc = dev_alloc(h, &st.cur, B))) return rc;
     if ((rc = dev_alloc(h, &st.evals, B))) return rc;
     if ((rc = dev_alloc(h, &st.s_bb, (size_t)B * 2 * S * 2 * MAXW, false))) return rc;
@@ -1585,6 +1585,20 @@ extern "C" int azg_arena_stats(azg_handle *h, int64_t *moved_to_large, int64_t *
     memcpy(v, h->h_static_bad + 4, sizeof(v));
     if (moved_to_large) *moved_to_large = (int64_t)v[0];
     if (trees_dropped) *trees_dropped = (int64_t)v[1];
+    return AZG_OK;
+}
+
+extern "C" int azg_reroot_stats(azg_handle *h, int64_t *in_place, int64_t *compacted)
+{
+    if (!h) return AZG_EINVAL;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    unsigned long long v[2] = {0, 0};
+    hipStream_t s = (h->sp.active && h->sp.copy_stream) ? h->sp.copy_stream : h->stream;
+    HIPCHK(h, hipMemcpyAsync(h->h_static_bad + 8, h->st.arena_stats + 2, sizeof(v), hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipStreamSynchronize(s));
+    memcpy(v, h->h_static_bad + 8, sizeof(v));
+    if (in_place) *in_place = (int64_t)v[0];
+    if (compacted) *compacted = (int64_t)v[1];
     return AZG_OK;
 }
 

@@ -303,6 +303,12 @@ class SelfPlayEngine:
         self._chk(self.L.azg_arena_stats(self.h, C.byref(a), C.byref(b)))
         return a.value, b.value
 
+    def reroot_stats(self):
+        """(re-roots that left the kept subtree in place, re-roots that compacted it) since creation."""
+        a, b = C.c_int64(0), C.c_int64(0)
+        self._chk(self.L.azg_reroot_stats(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def host_timing(self):
         """(host milliseconds spent drawing exploration noise, move steps) since the last call."""
         a, b = C.c_double(0.0), C.c_int64(0)

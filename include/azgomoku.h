@@ -249,6 +249,12 @@ int azg_profile(azg_handle *h, int64_t *launches, double *ms, int64_t *playouts)
  * the carried-over statistics).  Counts since azg_create: games moved, trees dropped. */
 int azg_arena_stats(azg_handle *h, int64_t *moved_to_large, int64_t *trees_dropped);
 
+/* MCTS.update_with_move (mcts_alphaZero.py:183-192) keeps the subtree of the move played.  Counts
+ * since azg_create: re-roots that left the kept subtree where it was (the child's record moved to
+ * the root's place), and re-roots that compacted it into the game's other arena because the arena
+ * had no room for another search behind what it held.  Both give the same tree. */
+int azg_reroot_stats(azg_handle *h, int64_t *in_place, int64_t *compacted);
+
 /* Host-side cost of the exploration noise (the numpy-legacy Dirichlet and uniform draws of
  * mcts_alphaZero.py:236-240, generated on host threads while a search runs): summed wall
  * milliseconds and number of move steps since the last call.  Resets the counters. */

@@ -305,6 +305,30 @@ def test_trees_that_outgrow_their_arena_move_to_a_large_one(az, oracle):
     eng.close()
 
 
+@pytest.mark.parametrize("n,k,npo,nodes,peaked", [(8, 5, 100, 260, False), (8, 5, 100, 1000, False), (6, 4, 64, 100, True),
+                                                  (6, 4, 64, 150, True), (15, 5, 120, 330, False)])
+def test_reroot_in_place_alternating_with_compaction(az, oracle, n, k, npo, nodes, peaked):
+    """MCTS.update_with_move (mcts_alphaZero.py:183-192) keeps the subtree of the move played.  Here
+    the child's record moves to the root's place and its subtree stays where it is while the arena has
+    room for one more search; when it has not, the subtree is compacted into the other arena, and when
+    even that is too small the game moves to a large arena.  Arenas of 2.5 to 10 searches make these
+    cases alternate within one game (flat and peaked priors, child blocks wider than a wave at 15x15);
+    every search must equal the oracle's, visit for visit, Q for Q."""
+    S = n * n
+
+    def peaked_policy(b):
+        low = min(b.avail[i] for i in range(b.n_avail)) if b.n_avail else -1
+        return [0.9375 if c == low else 0.0009765625 for c in range(S)], 0.0
+    eng = az.SelfPlayEngine(n, k, npo, 2, prior_mode=az.PRIOR_PEAKED if peaked else az.PRIOR_HASH, arena_nodes=nodes)
+    eng.reset_games()
+    plies = _forced_line(az, oracle, eng, peaked_policy if peaked else "hash", n, k, npo, 24, (0, 1))
+    assert plies >= 6 and eng.arena_stats()[1] == 0
+    in_place, compacted = eng.reroot_stats()
+    # (the move that ends the game starts a fresh root instead)
+    assert in_place >= 4 and compacted >= 2 and in_place + compacted in (2 * plies, 2 * plies + 2), (in_place, compacted, plies)
+    eng.close()
+
+
 @pytest.mark.parametrize("n,k,npo", [(8, 5, 1500), (15, 5, 600)])
 def test_reroot_with_a_small_work_stack(az, oracle, n, k, npo, monkeypatch):
     """MCTS.update_with_move (mcts_alphaZero.py:183-192): the subtree copy keeps its work list of
