@@ -8,7 +8,11 @@ import alphazero_gomoku_amd as az
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 eng = az.SelfPlayEngine(n, 5, int(os.environ.get("PLAYOUTS", 400 if n == 8 else 200)), B, cnn_mode=int(os.environ.get("CNN_MODE", "0")))
-eng.set_weights(helpers.make_params(n, seed=100 + n))
+if os.environ.get("MODEL"):              # a trained net instead of random weights: deep, narrow trees
+    from alphazero_gomoku_amd.net import PolicyValueNet
+    PolicyValueNet(n, n, model_file=os.environ["MODEL"]).sync_engine(eng, -1)
+else:
+    eng.set_weights(helpers.make_params(n, seed=100 + n))
 from alphazero_gomoku_amd.engine import SelfPlayRunner
 run = SelfPlayRunner(eng, temp=1.0, seed0=0, total=None, on_samples=None, device_samples=False)
 run.start()
