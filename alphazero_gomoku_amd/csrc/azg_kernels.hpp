@@ -103,6 +103,7 @@ __device__ __forceinline__ void search_body(DevState st)
         gl->big = st.big_of[g];
         gl->cap = arena_cap(st, g);
         gl->root_act = meta_act(tree_view(st, g, st.cur[g]).meta[0]);
+        for (int l = 0; l < 4; l++) { gl->spec_blk[l] = -1; gl->spec_k[l] = 0; }
     }
     wave_sync();
     long long n_eval = 0;
@@ -116,7 +117,8 @@ __device__ __forceinline__ void search_body(DevState st)
         int term = 0;
         if (active) {
             const TreeView tv = tree_view(st, g, gl->arena, gl->big);
-            d = wave_select<GL, false, (MODE == 0 ? (N * N + WAVE - 1) / WAVE : MAXS / WAVE)>(st, tv, gl, lane);
+            if constexpr (MODE == 0 && N * N <= WAVE && AZG_SPEC_LEVELS > 0) d = wave_select_spec<GL>(st, tv, gl, lane);
+            else d = wave_select<GL, false, (MODE == 0 ? (N * N + WAVE - 1) / WAVE : MAXS / WAVE)>(st, tv, gl, lane);
             // (with n_in_row < 3 a line can exist before the reference's n_in_row + 2 stone threshold
             // lets it count, so it need not contain the last stone: full scan there)
             if (d.depth > 1 && st.n_in_row >= 3 && st.n_in_row <= 8)

@@ -47,6 +47,7 @@ struct GameLdsT {
     int gid;                   // slot index
     int big;                   // large arena the game lives in, or -1 (DevState::big_of during a launch)
     int cap;                   // edges the game's arena holds
+    int spec_blk[4], spec_k[4];   // child blocks (first edge, children) the last descent went through below the root's, or -1
 };
 typedef GameLdsT<MAXS + 1> GameLds;
 
@@ -322,6 +323,104 @@ __device__ inline Descent wave_select(const DevState &st, const TreeView &t, GL 
             gl->path[depth] = e;
             gl->path_n[depth] = Np;
             gl->path_q[depth] = qsel;
+        }
+        depth++;
+        ply++;
+        last = act;
+    }
+    if (lane == 0) { gl->depth = depth; gl->leaf = e; gl->leaf_ply = ply; gl->leaf_last = last; }
+    wave_sync();
+    Descent d;
+    d.leaf = e; d.depth = depth; d.ply = ply; d.last = last;
+    return d;
+}
+
+// The same descent for boards of at most 64 cells (one child per lane), with the loads of the first
+// levels issued TOGETHER: consecutive playouts of a game mostly share the top of their path (always
+// with a peaked prior), so next to the root's child block the blocks the previous descent went
+// through at the next AZG_SPEC_LEVELS levels are requested at once.  A level whose block is the
+// guessed one finds its children in registers; any other level loads them as wave_select does.
+// What a block holds is read after the previous playout's backup either way and blocks never move
+// during a search, so the guess decides only WHEN data arrives, never what is chosen.
+// Exact (every parity test passes on a build with it) and measured SLOWER on one machine, two
+// interleaved rounds: with a trained net 12.87 ms per launch against 12.69 ms (three levels; one level
+// 12.78), with the random-init net 11.60 against 11.50 -- so it is off (0) and wave_select is used.
+#ifndef AZG_SPEC_LEVELS
+#define AZG_SPEC_LEVELS 0
+#endif
+template <class GL>
+__device__ inline Descent wave_select_spec(const DevState &st, const TreeView &t, GL *gl, int lane)
+{
+    constexpr int SP = AZG_SPEC_LEVELS + 1;                      // entry 0: the root's child block
+    static_assert(AZG_SPEC_LEVELS >= 0 && AZG_SPEC_LEVELS <= 4, "spec_blk holds four levels");
+    if (lane < 2 * MAXW) ((u64 *)gl->leaf_bb)[lane] = ((u64 *)gl->root_bb)[lane];
+    wave_sync();
+    int e = 0;
+    int depth = 1;
+    int ply = gl->root_ply, last = gl->root_last;
+    int child = t.child[0];
+    int K = meta_k(t.meta[0]);
+    int Np = t.N[0];
+    const double q0 = t.Q[0];
+    int sb[SP], sk[SP];
+    double sq_[SP];
+    float sp_[SP];
+    int sn_[SP], sc_[SP];
+    unsigned sm_[SP];
+    sb[0] = child; sk[0] = K;
+#pragma unroll
+    for (int l = 1; l < SP; l++) { sb[l] = gl->spec_blk[l - 1]; sk[l] = gl->spec_k[l - 1]; }
+#pragma unroll
+    for (int l = 0; l < SP; l++) {
+        sq_[l] = 0.0; sp_[l] = 0.0f; sn_[l] = 0; sc_[l] = -1; sm_[l] = 0;
+        if (sb[l] > 0) {                                         // wave-uniform
+            const int ei = sb[l] + (lane < sk[l] ? lane : 0);
+            sq_[l] = t.Q[ei]; sp_[l] = t.P[ei]; sn_[l] = t.N[ei]; sc_[l] = t.child[ei]; sm_[l] = t.meta[ei];
+        }
+    }
+    if (lane == 0) { gl->path[0] = 0; gl->path_n[0] = Np; gl->path_q[0] = q0; }
+    int level = 0;
+    while (child >= 0) {
+        const double sq = sqrt((double)Np);                      // np.sqrt(parent._n_visits)
+        double q = 0.0;
+        float p = 0.0f;
+        int n = 0, ch = -1;
+        unsigned mt = 0;
+        bool hit = false;
+#pragma unroll
+        for (int l = 0; l < SP; l++)
+            if (level == l && child == sb[l]) { q = sq_[l]; p = sp_[l]; n = sn_[l]; ch = sc_[l]; mt = sm_[l]; hit = true; }
+        if (!hit) {
+            const int ei = child + (lane < K ? lane : 0);
+            q = t.Q[ei]; p = t.P[ei]; n = t.N[ei]; ch = t.child[ei]; mt = t.meta[ei];
+        }
+        const bool any_visited = __ballot(lane < K && n != 0) != 0ULL;
+        double best = -HUGE_VAL;
+        int bidx = 0x7fffffff;
+        if (lane < K) {
+            // get_value (:82-83): c_puct * P * sqrt(Np) / (1 + n), left to right, then Q + u
+            const double num = (st.c_puct * (double)p) * sq;
+            const double u = any_visited ? num / (double)(1 + n) : num;
+            best = q + u;
+            bidx = lane;
+        }
+        const double rs = wave_max_f64(best);
+        const int ri = min(wave_min_i32(best == rs ? bidx : 0x7fffffff), K - 1);
+        e = child + ri;
+        child = __builtin_amdgcn_readlane(ch, ri);
+        Np = __builtin_amdgcn_readlane(n, ri);
+        const double qsel = lane_value_f64(q, ri);
+        const unsigned mtsel = (unsigned)__builtin_amdgcn_readlane((int)mt, ri);
+        K = meta_k(mtsel);
+        const int act = meta_act(mtsel);
+        level++;
+        if (lane == 0) {
+            const int mover = player_at(gl->first_player, ply);
+            gl->leaf_bb[mover - 1][act >> 6] |= 1ULL << (act & 63);
+            gl->path[depth] = e;
+            gl->path_n[depth] = Np;
+            gl->path_q[depth] = qsel;
+            if (level < SP && child >= 0) { gl->spec_blk[level - 1] = child; gl->spec_k[level - 1] = K; }
         }
         depth++;
         ply++;
