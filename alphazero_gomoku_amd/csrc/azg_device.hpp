@@ -235,6 +235,7 @@ struct Prof {
         last = t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime();
     }
     __device__ void mark(int i) { if (on) { const long long now = __builtin_amdgcn_s_memtime(); acc[i] += (unsigned)(now - last); last = now; } }
+    __device__ void count(int i, int v) { if (on) acc[i] += (unsigned)v; }      // a plain counter in slot i
     // slots 30 / 31: shader cycles and 100 MHz ticks of the whole loop (their ratio is the clock held)
     __device__ void finish()
     {
@@ -251,6 +252,7 @@ struct Prof {
 #else
     __device__ void start(long long *, int = 0) {}
     __device__ void mark(int) {}
+    __device__ void count(int, int) {}
     __device__ void finish() {}
 #endif
 };

@@ -128,6 +128,7 @@ __device__ __forceinline__ void search_body(DevState st)
             else term = wave_game_end(gl->leaf_bb, st.N, st.S, st.n_in_row, d.ply, lane);
             if (lane == 0) { gl->term = term; gl->need_eval = term == 0; }
             n_eval += term == 0;
+            prof.count(18, d.depth);
         }
         prof.mark(0);
         if (MODE == 0) {

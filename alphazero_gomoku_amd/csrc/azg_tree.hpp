@@ -114,6 +114,17 @@ __device__ inline double wave_max_f64(double v)
     return fmax(fmax(lane_value_f64(v, 0), lane_value_f64(v, 16)), fmax(lane_value_f64(v, 32), lane_value_f64(v, 48)));
 }
 
+__device__ inline float tree_wave_max_f32(float v)
+{
+    v = fmaxf(v, __int_as_float(dpp_int<DPP_XOR1>(__float_as_int(v))));
+    v = fmaxf(v, __int_as_float(dpp_int<DPP_XOR2>(__float_as_int(v))));
+    v = fmaxf(v, __int_as_float(dpp_int<DPP_HALF_MIRROR>(__float_as_int(v))));
+    v = fmaxf(v, __int_as_float(dpp_int<DPP_MIRROR>(__float_as_int(v))));
+    const int b = __float_as_int(v);
+    return fmaxf(fmaxf(__int_as_float(__builtin_amdgcn_readlane(b, 0)), __int_as_float(__builtin_amdgcn_readlane(b, 16))),
+                 fmaxf(__int_as_float(__builtin_amdgcn_readlane(b, 32)), __int_as_float(__builtin_amdgcn_readlane(b, 48))));
+}
+
 __device__ inline int wave_min_i32(int v)
 {
     v = min(v, dpp_int<DPP_XOR1>(v));
@@ -248,6 +259,9 @@ __device__ inline int game_end_1w(u64 s1, u64 s2, int N, int S, int nrow, int ns
 // caller's board can need.  UNIFORM_P: every child of a
 // node carries the prior 1/K in double (the rollout opponent's policy_value_fn,
 // mcts_pure.py:33-46), computed instead of loaded.
+#ifndef AZG_SELECT_SCREEN
+#define AZG_SELECT_SCREEN 1       // 0: every level takes the double-precision pass
+#endif
 template <class GL, bool UNIFORM_P = false, int CPL = MAXS / WAVE>
 __device__ inline Descent wave_select(const DevState &st, const TreeView &t, GL *gl, int lane)
 {
@@ -263,7 +277,6 @@ __device__ inline Descent wave_select(const DevState &st, const TreeView &t, GL 
     const double q0 = t.Q[0];
     if (lane == 0) { gl->path[0] = 0; gl->path_n[0] = Np; gl->path_q[0] = q0; }
     while (child >= 0) {
-        const double sq = sqrt((double)Np);                      // np.sqrt(parent._n_visits)
         double best = -HUGE_VAL, bq = 0.0;
         int bidx = 0x7fffffff, bchild = -1, bn = 0;
         unsigned bmeta = 0;
@@ -286,6 +299,42 @@ __device__ inline Descent wave_select(const DevState &st, const TreeView &t, GL 
                 mt_[c] = t.meta[ei];
             }
         }
+        // Screen in single precision: the same score evaluated in float32 differs from the double
+        // one by less than 5.4e-7 * (1 + |largest score|) (two roundings in c_puct * P, one each in
+        // sqrt, its product, the reciprocal, its product, the conversion of Q and the sum; |Q| <= 1,
+        // u >= 0).  A child whose float32 score stands more than 4e-6 * (1 + |max|) clear of every
+        // other child's -- over three times twice that bound -- is therefore the maximum of the
+        // double scores too, and the double-precision pass (square root, division, 64-bit wave
+        // maximum: the bulk of a level's instructions) is skipped.  Ties and near-ties take that pass.
+        int ri_screen = -1;
+        if (AZG_SELECT_SCREEN && !UNIFORM_P) {
+            const float sq32 = __builtin_sqrtf((float)Np), c32 = (float)st.c_puct;
+            float s32_[CPL];
+            float b32 = -HUGE_VALF;
+#pragma unroll
+            for (int c = 0; c < CPL; c++) {
+                const int i = lane + c * WAVE;
+                s32_[c] = -HUGE_VALF;
+                if (c * WAVE < K && i < K) {
+                    s32_[c] = (float)q_[c] + ((c32 * p_[c]) * sq32) * __builtin_amdgcn_rcpf((float)(1 + n_[c]));
+                    b32 = fmaxf(b32, s32_[c]);
+                }
+            }
+            const float m32 = tree_wave_max_f32(b32);
+            const float bar = m32 - 4e-6f * (1.0f + fabsf(m32));
+            int near = 0, at = -1;
+#pragma unroll
+            for (int c = 0; c < CPL; c++) {
+                if (c * WAVE < K) {                              // wave-uniform
+                    const u64 mk = __ballot(lane + c * WAVE < K && s32_[c] >= bar);
+                    near += __popcll(mk);
+                    if (mk && at < 0) at = c * WAVE + __ffsll((long long)mk) - 1;
+                }
+            }
+            if (near == 1 && m32 < HUGE_VALF && m32 > -HUGE_VALF) ri_screen = at;
+        }
+        if (ri_screen < 0) {
+        const double sq = sqrt((double)Np);                      // np.sqrt(parent._n_visits)
 #pragma unroll
         for (int c = 0; c < CPL; c++) {
             const int i = lane + c * WAVE;
@@ -304,10 +353,20 @@ __device__ inline Descent wave_select(const DevState &st, const TreeView &t, GL 
         }
         // first maximum in ascending child order: the wave maximum, then the lowest child index
         // among the lanes that hold it (a lane already kept its own first maximum)
-        const double rs = wave_max_f64(best);
-        // (a score that compares with nothing -- a NaN -- would leave no lane holding the maximum;
-        // the index is kept inside the node's block whatever the scores are)
-        const int ri = min(wave_min_i32(best == rs ? bidx : 0x7fffffff), K - 1);
+        }
+        int ri;
+        if (ri_screen >= 0) {
+            ri = ri_screen;
+            // the lane that holds child ri hands over that child's fields
+#pragma unroll
+            for (int c = 0; c < CPL; c++)
+                if (c == (ri >> 6)) { bq = q_[c]; bchild = ch_[c]; bn = n_[c]; bmeta = mt_[c]; }
+        } else {
+            const double rs = wave_max_f64(best);
+            // (a score that compares with nothing -- a NaN -- would leave no lane holding the maximum;
+            // the index is kept inside the node's block whatever the scores are)
+            ri = min(wave_min_i32(best == rs ? bidx : 0x7fffffff), K - 1);
+        }
         const int src = ri & 63;
         e = child + ri;
         child = __builtin_amdgcn_readlane(bchild, src);

@@ -33,9 +33,10 @@ ngroups = (B + 1) // 2 if (n <= 8 or os.environ.get("DUAL")) else B          # w
 per_group = 4 if n <= 8 else (2 if os.environ.get("DUAL") else 1)             # playouts per workgroup iteration
 raw = list(out)
 out = [v / ngroups for v in out]
+depth_sum = out[18]; out[18] = 0.0                     # slot 18 counts path entries (root .. leaf) of wave 0's descents
 tot = sum(out[:20])
 print("launches", l, "ms/launch", ms / l, "cycles/playout", tot / (4 * eng.n_playout),
-      "clock GHz", out[30] / max(1, out[31]) * 0.1)
+      "clock GHz", out[30] / max(1, out[31]) * 0.1, "path entries per descent (root .. leaf)", depth_sum / (4 * eng.n_playout))
 if os.environ.get("DUAL"):
     # two-wave-group kernel: thread 0 stamps the net waves, thread 256 the tree waves; per leaf evaluation
     names = {1: "net: wait for a leaf", 14: "net: conv2 setup", 15: "net: conv2 k-loop", 17: "net: conv2 epilogue", 4: "net: sync + a1gen",
