@@ -262,9 +262,24 @@ __device__ inline int game_end_1w(u64 s1, u64 s2, int N, int S, int nrow, int ns
 #ifndef AZG_SELECT_SCREEN
 #define AZG_SELECT_SCREEN 1       // 0: every level takes the double-precision pass
 #endif
+#ifndef AZG_SELECT_PRIO
+// A descent that goes deep (a trained net: six path entries on average instead of three) holds up its
+// workgroup's whole playout iteration while the partner workgroup's dense loops, at priority 2, take
+// the issue slots of the shared SIMDs.  From the third level below the root on it runs at priority 3:
+// same-box A/B, two interleaved rounds: trained net 11.99 -> 11.59 ms per launch, random-init
+// benchmark 11.06 -> 11.02 (from the start of the descent: 11.63 and 11.15, the benchmark loses).
+#define AZG_SELECT_PRIO 3         // > 0: the descent runs at this issue priority (the dense loops of the CNN run at 2) ...
+#endif
+#ifndef AZG_SELECT_PRIO_LEVEL
+#define AZG_SELECT_PRIO_LEVEL 3   // ... from this level below the root on (0: from the start)
+#endif
 template <class GL, bool UNIFORM_P = false, int CPL = MAXS / WAVE>
 __device__ inline Descent wave_select(const DevState &st, const TreeView &t, GL *gl, int lane)
 {
+    // (only the one-child-per-lane kernels, where the descent shares its SIMD with a partner workgroup's
+    // dense loops; in the two-wave-group kernel of the larger boards it measured 2.5 % slower)
+    constexpr bool RAISE = AZG_SELECT_PRIO > 0 && CPL == 1 && !UNIFORM_P;
+    if (RAISE && AZG_SELECT_PRIO_LEVEL == 0) __builtin_amdgcn_s_setprio(AZG_SELECT_PRIO);
     // leaf board starts as a copy of the root board (copy.deepcopy, :162)
     if (lane < 2 * MAXW) ((u64 *)gl->leaf_bb)[lane] = ((u64 *)gl->root_bb)[lane];
     wave_sync();
@@ -277,6 +292,7 @@ __device__ inline Descent wave_select(const DevState &st, const TreeView &t, GL 
     const double q0 = t.Q[0];
     if (lane == 0) { gl->path[0] = 0; gl->path_n[0] = Np; gl->path_q[0] = q0; }
     while (child >= 0) {
+        if (RAISE && AZG_SELECT_PRIO_LEVEL > 0 && depth == 1 + AZG_SELECT_PRIO_LEVEL) __builtin_amdgcn_s_setprio(AZG_SELECT_PRIO);
         double best = -HUGE_VAL, bq = 0.0;
         int bidx = 0x7fffffff, bchild = -1, bn = 0;
         unsigned bmeta = 0;
@@ -389,6 +405,7 @@ __device__ inline Descent wave_select(const DevState &st, const TreeView &t, GL 
     }
     if (lane == 0) { gl->depth = depth; gl->leaf = e; gl->leaf_ply = ply; gl->leaf_last = last; }
     wave_sync();
+    if (RAISE) __builtin_amdgcn_s_setprio(0);
     Descent d;
     d.leaf = e; d.depth = depth; d.ply = ply; d.last = last;
     return d;
