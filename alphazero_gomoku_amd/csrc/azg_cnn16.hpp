@@ -387,6 +387,27 @@ __device__ inline void conv3x3_f16(const half8 *wp, WRing<RING, CW> &ring, const
     if (COUT >= 64) azg_simd_gate_release();
 #endif
     if (prof) prof->mark(slot);
+#ifdef AZG_EXP_LANE0
+    // Hazard experiment: an LDS store directly behind the unrolled MFMA loop, into a padding word of the
+    // constants block.  1: by lane 0 alone (volatile: the address stays generic, flat_store_dword);
+    // 5: by lane 0 alone as a genuine ds_write_b32; 3: by every lane.  Measured at 8x8: with 1 and 5 the
+    // EVALUATION kernel's probabilities are off by 1.2e-3 (the same value every time, also with 32 wait
+    // states or a full counter drain in front of the branch), the search kernel of the same build is
+    // exact; with 3 both are exact.  Deterministic and indifferent to timing: generated code, not a
+    // hardware wait-state window (the pair v_mfma_f32_32x32x16_f16 -> VALU read needs 12 wait states on
+    // this part, which is what the compiler pads: tests/micro/mfma_read_wait.hip).
+    {
+        extern __shared__ __attribute__((aligned(16))) float azg_exp_lds[];
+        float *pad = azg_exp_lds + kLdsHead + G::BIAS_OFF / 4 + G::B_VFC2 + 4;
+        if (AZG_EXP_LANE0 == 5) {
+            if (lane == 0) {
+                __attribute__((address_space(3))) float *p3 = (__attribute__((address_space(3))) float *)pad;
+                *p3 = 1.0f;
+                asm volatile("" ::: "memory");
+            }
+        } else if (AZG_EXP_LANE0 == 3 || lane == 0) *reinterpret_cast<volatile float *>(pad) = 1.0f;
+    }
+#endif
     // prep() reads what every tile's epilogue needs from LDS once, before the first epilogue
     // store (the compiler must assume a later read could alias such a store and would
     // otherwise serialise read -> wait -> compute -> store per group of values)
@@ -857,7 +878,10 @@ __device__ inline void cnn16_tail_sparse(const NetWeights &nw, float *lds, int t
 #pragma unroll
             for (int u = 0; u < U; u++)
 #pragma unroll
-                for (int j = 0; j < 4; j++) acc[j] = __builtin_fmaf(wv[u][j], xv[u], acc[j]);
+                for (int j = 0; j < 4; j++) {
+                    acc[j] = __builtin_fmaf(wv[u][j], xv[u], acc[j]);
+                    asm volatile("" : "+v"(acc[j]));          // never two-wide (see the note at AZG_EXP_PKFC, azg_dual.hpp)
+                }
         }
         *reinterpret_cast<f32x4 *>(lds + G::SPP_OFF + wave * 256 + 4 * lane) = acc;
     }
@@ -879,7 +903,10 @@ __device__ inline void cnn16_tail_sparse(const NetWeights &nw, float *lds, int t
 #pragma unroll
             for (int u = 0; u < 8; u++)
 #pragma unroll
-                for (int j = 0; j < 4; j++) acc[j] = __builtin_fmaf(wv[u][j], xv[u], acc[j]);
+                for (int j = 0; j < 4; j++) {
+                    acc[j] = __builtin_fmaf(wv[u][j], xv[u], acc[j]);
+                    asm volatile("" : "+v"(acc[j]));
+                }
         }
         *reinterpret_cast<f32x4 *>(lds + G::SPV_OFF + (wave * 4 + grp) * 64 + 4 * l16) = acc;
     }

@@ -94,8 +94,12 @@ __device__ inline NetWeights opaque_weights(const NetWeights &w)
 // fall into opposite phase.  The gate is advisory: the wait is bounded and results never
 // depend on it (a workgroup that gives up just runs its convolutions beside the partner's).
 // The table is shared by every engine of the process on a device, so workgroups of two
-// engines that run concurrently on separate streams pair up the same way.
+// engines that run concurrently on separate streams pair up the same way.  azg_create and
+// azg_selfplay_begin clear it (a launch that died inside a gated span would otherwise leave words
+// set); a workgroup that gives up waiting counts that in g_gate_giveups, and its release() frees the
+// word again, so a word left set costs one bounded wait per CU, not one per playout.
 __device__ int g_matrix_gate[kGateWords];
+__device__ unsigned int g_gate_giveups[4];    // [0]: acquires that ran out of tries since the process started
 
 // Experiment builds (-DAZG_QUAD8=1, 8x8 only): ONE 512-thread workgroup per CU holds both game
 // pairs, as two groups of four waves that run the per-pair code independently on their own LDS
@@ -207,6 +211,7 @@ struct MatrixGate {
             if (AZG_QUAD8) __builtin_amdgcn_s_sleep(1); else __builtin_amdgcn_s_sleep(16);
         }
 #endif
+        atomicAdd(&g_gate_giveups[0], 1u);         // the convolutions run beside the partner's this once
     }
     // thread 0 of the workgroup, after a workgroup barrier
     __device__ void release() const

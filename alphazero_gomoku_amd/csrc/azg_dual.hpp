@@ -155,6 +155,23 @@ struct DualGeom : Cnn16Geom<N_, T_> {
 #ifndef AZG_DUAL_TAIL_SYNC
 #define AZG_DUAL_TAIL_SYNC 0 // 1: a barrier of the tree waves behind the softmax (measured: not needed, costs ~0.6 k cycles per evaluation)
 #endif
+// Two-wide float32 arithmetic (v_pk_fma_f32) is kept out of these kernels.  Formed by the SLP
+// vectoriser from the sparse policy layer's multiply-adds, the FIRST row's operation takes its x as the
+// high dword of the (row index, x) register pair the list read returned (op_sel:[0,1,0]); on the tree
+// waves, beside the matrix-dense net waves, the low half of the second such operation then comes out
+// WITHOUT its product in lanes 48-55 in about one evaluation in a hundred (the low dword of the pair,
+// an integer, read in place of x gives exactly that: a product below rounding).  Measured: 50-70 of 256
+// identical searches wrong with the vectoriser on, or with only this loop written two-wide
+// (-DAZG_EXP_PKFC=1); none when that one x is first moved out of its pair (-DAZG_EXP_PKFC=6, same
+// waits, same registers otherwise), none with single-lane sums under the vectoriser.  It is not a
+// late load (the single-lane sum from the same registers is right, and so is the two-wide one when
+// every load is waited for), not register spilling, not the issue priorities; the same instruction
+// forms in a stand-alone kernel beside MFMA-issuing waves are exact (tests/micro/pk_fma_beside_mfma.hip).
+// The sums below are written so that no vectoriser can pair them, the library is built with
+// -fno-slp-vectorize, and build.sh fails on any v_pk_*_f32 in the device code.
+#ifndef AZG_EXP_PKFC
+#define AZG_EXP_PKFC 0       // 1 / 6: the experiment builds described above
+#endif
 #ifndef AZG_FC_NT
 #define AZG_FC_NT 0          // 1: the sparse FC reads its weight rows with the non-temporal hint
 #endif
@@ -399,10 +416,32 @@ __device__ inline bool dual_tail(const NetWeights &nw_in, float *lds, float *tl,
                 xv[u] = i0 + u < np ? e.x : 0.0f;
                 wv[u] = AZG_FC_LOAD(wrow + (size_t)e.k * 64);
             }
+#if AZG_EXP_PKFC == 1 || AZG_EXP_PKFC == 6
+            // Hazard experiment (SLP vectoriser off everywhere else): the same multiply-adds as explicit
+            // two-wide operations.  1: as the vectoriser forms them -- the first row's x stays the HIGH dword
+            // of the (row index, x) pair the list read returned, selected with op_sel:[0,1,0]: sums come out
+            // one term short in lanes 48-55.  6: the same, but that x is moved out of its pair first
+            // (op_sel_hi:[1,0,1] like every other row): exact.
+            {
+                if (AZG_EXP_PKFC == 6) asm volatile("" : "+v"(xv[0]));
+                f32x2 a01 = {acc[0], acc[1]}, a23 = {acc[2], acc[3]};
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    const f32x2 x2 = {xv[u], xv[u]}, w01 = {wv[u][0], wv[u][1]}, w23 = {wv[u][2], wv[u][3]};
+                    a01 = __builtin_elementwise_fma(w01, x2, a01);
+                    a23 = __builtin_elementwise_fma(w23, x2, a23);
+                }
+                acc[0] = a01[0]; acc[1] = a01[1]; acc[2] = a23[0]; acc[3] = a23[1];
+            }
+#else
 #pragma unroll
             for (int u = 0; u < U; u++)
 #pragma unroll
-                for (int jj = 0; jj < 4; jj++) acc[jj] = __builtin_fmaf(wv[u][jj], xv[u], acc[jj]);
+                for (int jj = 0; jj < 4; jj++) {
+                    acc[jj] = __builtin_fmaf(wv[u][jj], xv[u], acc[jj]);
+                    asm volatile("" : "+v"(acc[jj]));         // never two-wide: see the note at AZG_EXP_PKFC
+                }
+#endif
         }
         wave_sync();                                          // the policy list is dead: its place takes the sums
         *reinterpret_cast<f32x4 *>(yw + 4 * lane) = acc;
@@ -425,7 +464,10 @@ __device__ inline bool dual_tail(const NetWeights &nw_in, float *lds, float *tl,
 #pragma unroll
             for (int u = 0; u < 8; u++)
 #pragma unroll
-                for (int jj = 0; jj < 4; jj++) acc[jj] = __builtin_fmaf(wv[u][jj], xv[u], acc[jj]);
+                for (int jj = 0; jj < 4; jj++) {
+                    acc[jj] = __builtin_fmaf(wv[u][jj], xv[u], acc[jj]);
+                    asm volatile("" : "+v"(acc[jj]));         // never two-wide: see the note at AZG_EXP_PKFC
+                }
         }
         wave_sync();                                          // both lists are dead now
         *reinterpret_cast<f32x4 *>(yw + 256 + grp * 64 + 4 * l16) = acc;

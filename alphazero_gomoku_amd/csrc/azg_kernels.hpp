@@ -255,7 +255,8 @@ __global__ __launch_bounds__(64) void playout_select_kernel(DevState st, int g, 
     }
     wave_sync();
     const TreeView tv = tree_view(st, g, gl->arena, gl->big);
-    const Descent d = wave_select<GameLds, false, MAXS / WAVE>(st, tv, gl, lane);
+    // (no float32 screen: the caller's values and priors may lie outside the range its margin assumes)
+    const Descent d = wave_select<GameLds, false, MAXS / WAVE, false>(st, tv, gl, lane);
     const int term = wave_game_end(gl->leaf_bb, st.N, st.S, st.n_in_row, d.ply, lane);
     if (lane == 0) { gl->term = term; gl->need_eval = term == 0; }
     wave_sync();

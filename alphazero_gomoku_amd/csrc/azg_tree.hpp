@@ -273,7 +273,10 @@ __device__ inline int game_end_1w(u64 s1, u64 s2, int N, int S, int nrow, int ns
 #ifndef AZG_SELECT_PRIO_LEVEL
 #define AZG_SELECT_PRIO_LEVEL 3   // ... from this level below the root on (0: from the start)
 #endif
-template <class GL, bool UNIFORM_P = false, int CPL = MAXS / WAVE>
+// SCREEN: the float32 screen in front of the double-precision pass (below).  Its margin is derived
+// for |Q| <= 1 and priors in [0, 1], which the engine's own providers guarantee; the descent that
+// serves a caller-evaluated playout (arbitrary values and priors) is instantiated without it.
+template <class GL, bool UNIFORM_P = false, int CPL = MAXS / WAVE, bool SCREEN = true>
 __device__ inline Descent wave_select(const DevState &st, const TreeView &t, GL *gl, int lane)
 {
     // (only the one-child-per-lane kernels, where the descent shares its SIMD with a partner workgroup's
@@ -323,7 +326,7 @@ __device__ inline Descent wave_select(const DevState &st, const TreeView &t, GL 
         // double scores too, and the double-precision pass (square root, division, 64-bit wave
         // maximum: the bulk of a level's instructions) is skipped.  Ties and near-ties take that pass.
         int ri_screen = -1;
-        if (AZG_SELECT_SCREEN && !UNIFORM_P) {
+        if (AZG_SELECT_SCREEN && SCREEN && !UNIFORM_P) {
             const float sq32 = __builtin_sqrtf((float)Np), c32 = (float)st.c_puct;
             float s32_[CPL];
             float b32 = -HUGE_VALF;

@@ -118,6 +118,27 @@ static hipError_t static_scratch_ptr(int device, unsigned char **out)
     return hipSuccess;
 }
 
+// Device addresses of this GPU's matrix-gate table and give-up counter (azg_device.hpp), looked up
+// once per device like the scratch array's; the device must be current.
+static int *g_gate_ptr[kMaxDevices] = {nullptr};
+static unsigned *g_giveup_ptr[kMaxDevices] = {nullptr};
+static hipError_t gate_ptrs(int device, int **gate, unsigned **giveups)
+{
+    if (device < 0 || device >= kMaxDevices) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> lk(g_static_mutex);
+    if (!g_gate_ptr[device]) {
+        void *p = nullptr, *q = nullptr;
+        hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(g_matrix_gate));
+        if (e == hipSuccess) e = hipGetSymbolAddress(&q, HIP_SYMBOL(g_gate_giveups));
+        if (e != hipSuccess) return e;
+        g_gate_ptr[device] = static_cast<int *>(p);
+        g_giveup_ptr[device] = static_cast<unsigned *>(q);
+    }
+    *gate = g_gate_ptr[device];
+    *giveups = g_giveup_ptr[device];
+    return hipSuccess;
+}
+
 struct azg_handle {
     azg_config cfg{};
     DevState st{};
@@ -125,6 +146,8 @@ struct azg_handle {
     std::string err;
     std::vector<void *> allocs;
     unsigned char *static_scratch = nullptr;     // this device's copy of the file-scope scratch array
+    int *gate_table = nullptr;                   // this device's matrix-gate table (kGateWords words)
+    unsigned *gate_giveups = nullptr;            // and its give-up counter
     int *h_static_bad = nullptr;                 // pinned: illegal-move flag read back by the static entry point
     int playout_parked = -1;                     // slot with a playout between azg_playout_begin and azg_playout_end
     bool have_weights = false;
@@ -447,6 +470,10 @@ static int create_impl(azg_handle *h)
     HIPCHK(h, hipSetDevice(c.device));
     HIPCHK(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     HIPCHK(h, static_scratch_ptr(c.device, &h->static_scratch));
+    // the per-CU matrix gates start free: a launch of an earlier engine that died inside a gated
+    // span must not cost this one a bounded wait per CU
+    HIPCHK(h, gate_ptrs(c.device, &h->gate_table, &h->gate_giveups));
+    HIPCHK(h, hipMemsetAsync(h->gate_table, 0, kGateWords * sizeof(int), h->stream));
     HIPCHK(h, hipHostMalloc((void **)&h->h_static_bad, 64));   // [0] board-step flag, bytes 16..47 arena and re-root counters, [12] CNN range flag
     DevState &st = h->st;
     st.N = N; st.S = S; st.NW = (S + 63) / 64; st.n_in_row = c.n_in_row; st.B = B;
@@ -1333,6 +1360,7 @@ extern "C" int azg_selfplay_begin(azg_handle *h, double temp, uint32_t seed0, in
         seeds[g] = (uint32_t)((long long)seed0 + ids[g]);
         started++;
     }
+    HIPCHK(h, hipMemsetAsync(h->gate_table, 0, kGateWords * sizeof(int), h->stream));   // see create_impl
     int rc = azg_reset_games(h, mask.data(), seeds.data(), ids.data());
     if (rc) return rc;
     // slots that get no game must not keep an older one alive
@@ -1599,6 +1627,32 @@ extern "C" int azg_reroot_stats(azg_handle *h, int64_t *in_place, int64_t *compa
     memcpy(v, h->h_static_bad + 8, sizeof(v));
     if (in_place) *in_place = (int64_t)v[0];
     if (compacted) *compacted = (int64_t)v[1];
+    return AZG_OK;
+}
+
+extern "C" int azg_gate_stats(azg_handle *h, int64_t *giveups, int64_t *words_set)
+{
+    if (!h) return AZG_EINVAL;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    hipStream_t s = (h->sp.active && h->sp.copy_stream) ? h->sp.copy_stream : h->stream;
+    std::vector<int> words(kGateWords);
+    unsigned n = 0;
+    HIPCHK(h, hipMemcpyAsync(words.data(), h->gate_table, kGateWords * sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipMemcpyAsync(&n, h->gate_giveups, sizeof(n), hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipStreamSynchronize(s));
+    if (giveups) *giveups = (int64_t)n;
+    if (words_set) *words_set = (int64_t)std::count_if(words.begin(), words.end(), [](int w) { return w != 0; });
+    return AZG_OK;
+}
+
+extern "C" int azg_gate_poke(azg_handle *h, int value)
+{
+    if (!h) return AZG_EINVAL;
+    NOT_WHILE_PIPELINED(h);
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    std::vector<int> words(kGateWords, value);
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipMemcpy(h->gate_table, words.data(), kGateWords * sizeof(int), hipMemcpyHostToDevice));
     return AZG_OK;
 }
 

@@ -4,8 +4,11 @@
 #   order (no fused multiply-add).
 #  -fno-slp-vectorize keeps float32 arithmetic on single-lane VALU instructions.  Left on, -O3 packs
 #   adjacent multiply-adds into v_pk_fma_f32; in the kernel whose tree waves share their SIMDs with
-#   matrix-dense waves (azg_dual.hpp) such packed results came out one term short in lanes 48-63 of
-#   the low halves (measured: 98 of 256 identical searches differed, none without packing).
+#   matrix-dense waves such an operation, fed its x from the high dword of a register pair
+#   (op_sel:[0,1,0]), came out one term short in lanes 48-55 (50-70 of 256 identical searches wrong;
+#   the note at AZG_EXP_PKFC in azg_dual.hpp has the measurements).  The build FAILS when the device
+#   code holds any two-wide float32 instruction (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32), whatever
+#   flag or compiler version produced it.
 #  -no-hip-rt leaves the HIP runtime symbols undefined: the process must hold exactly ONE HIP
 #   runtime, and PyTorch ships its own libamdhip64.so.  The loader (alphazero_gomoku_amd/_lib.py)
 #   loads the runtime PyTorch will use (or /opt/rocm's when PyTorch is absent) with RTLD_GLOBAL
@@ -14,9 +17,18 @@ set -e
 here="$(cd "$(dirname "$0")" && pwd)"
 out="$here/../libazgomoku.so"
 log="$(mktemp)"
-hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fno-slp-vectorize -fPIC -shared -std=c++17 -Wall -no-hip-rt \
-    -Rpass-analysis=kernel-resource-usage \
-    "$here/azgomoku.hip" -o "$out" -lpthread "$@" 2> "$log" || { cat "$log" >&2; rm -f "$log"; exit 1; }
+tmp="$(mktemp -d)"
+trap 'rm -rf "$tmp"' EXIT
+# (the device assembly is kept as a by-product of the one compilation: -save-temps, in a scratch directory)
+( cd "$tmp" && hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fno-slp-vectorize -fPIC -shared -std=c++17 -Wall -no-hip-rt \
+    -Rpass-analysis=kernel-resource-usage -save-temps=cwd \
+    "$here/azgomoku.hip" -o "$out" -lpthread "$@" ) 2> "$log" || { cat "$log" >&2; rm -f "$log"; exit 1; }
+asm="$(ls "$tmp"/*gfx950.s 2>/dev/null | head -1)"
+if [ -z "$asm" ]; then echo "build.sh: no device assembly to check" >&2; rm -f "$out" "$log"; exit 1; fi
+if grep -nE "v_pk_(fma|mul|add)_f32" "$asm" | head -5 | grep . >&2; then
+    echo "build.sh: two-wide float32 instructions in the device code (see above): refusing to ship this library" >&2
+    rm -f "$out" "$log"; exit 1
+fi
 # compiler warnings, without the resource-usage remarks and their source excerpts
 if grep -q "warning:" "$log"; then
     awk '/kernel-resource-usage/ { skip = 2; next } skip > 0 { skip--; next } { print }' "$log" >&2

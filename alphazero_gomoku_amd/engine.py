@@ -309,6 +309,18 @@ class SelfPlayEngine:
         self._chk(self.L.azg_reroot_stats(self.h, C.byref(a), C.byref(b)))
         return a.value, b.value
 
+    def gate_stats(self):
+        """(waits for a CU's matrix gate that ran out since the process started on this GPU, gate
+        words set right now).  The gate only schedules (see azg_gate_stats); a count > 0 means slower
+        launches, never different results."""
+        a, b = C.c_int64(0), C.c_int64(0)
+        self._chk(self.L.azg_gate_stats(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def gate_poke(self, value):
+        """Diagnostic: store `value` in every word of this GPU's gate table."""
+        self._chk(self.L.azg_gate_poke(self.h, int(value)))
+
     def host_timing(self):
         """(host milliseconds spent drawing exploration noise, move steps) since the last call."""
         a, b = C.c_double(0.0), C.c_int64(0)

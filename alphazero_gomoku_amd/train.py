@@ -55,6 +55,17 @@ class TrainPipeline:
                       learning rate follow each other on a net that has not moved yet; with this and the
                       ceiling of 1, twenty of twenty differently seeded runs learned."""
 
+    @staticmethod
+    def controller_defaults(play_batch_size, max_lr_multiplier=None, zero_head_biases=None):
+        """(ceiling of the learning-rate multiplier, whether a fresh net gets its head-convolution
+        biases zeroed) for the given arguments.  With one game per batch both are the reference's
+        (ceiling 10 as in train.py:199, initialisation untouched); batched play deliberately
+        deviates (ceiling 1, zero head biases) unless told otherwise -- no reference fixture covers
+        that regime."""
+        batched = play_batch_size > 1
+        ceiling = float(max_lr_multiplier) if max_lr_multiplier is not None else (1.0 if batched else 10.0)
+        return ceiling, (batched if zero_head_biases is None else bool(zero_head_biases))
+
     def __init__(self, board_width=8, board_height=8, n_in_row=5, init_model=None, learn_rate=2e-3,
                  lr_multiplier=1.0, temp=1.0, n_playout=400, c_puct=5, buffer_size=10000, batch_size=512,
                  play_batch_size=1, epochs=5, kl_targ=0.02, check_freq=50, game_batch_num=1500,
@@ -73,13 +84,14 @@ class TrainPipeline:
         self.play_batch_size, self.epochs, self.kl_targ = play_batch_size, epochs, kl_targ
         self.check_freq, self.game_batch_num = check_freq, game_batch_num
         self.updates_per_batch, self.continuous = int(updates_per_batch), bool(continuous)
-        self.max_lr_multiplier = float(max_lr_multiplier) if max_lr_multiplier is not None else (10.0 if play_batch_size <= 1 else 1.0)
+        self.max_lr_multiplier, want_zero = self.controller_defaults(play_batch_size, max_lr_multiplier, zero_head_biases)
         self.best_win_ratio = 0.2                                            # train.py:88
         self.pure_mcts_playout_num = pure_mcts_playout_num
         fresh = policy_value_net is None and not init_model
         self.policy_value_net = policy_value_net or PolicyValueNet(board_width, board_height, model_file=init_model,
                                                                    device=device)
-        if fresh and (play_batch_size > 1 if zero_head_biases is None else zero_head_biases):
+        self.zeroed_head_biases = bool(fresh and want_zero)      # reported by the training program
+        if self.zeroed_head_biases:
             self.policy_value_net.zero_head_biases()
         self.device, self.seed0, self.games_played = device, seed0, 0
         self.rank, self.world = 0, 1
@@ -421,7 +433,10 @@ def main(argv=None):
                           "loss_curve": [round(losses[i], 3) for i in range(0, len(losses), max(1, len(losses) // 16))],
                           "entropy_first_last": [tp.loss_history[0][1], tp.loss_history[-1][1]] if tp.loss_history else None,
                           "win_ratio_vs_rollout_player": final, "rollout_playouts": tp.pure_mcts_playout_num,
-                          "lr_multiplier": tp.lr_multiplier, "max_lr_multiplier": tp.max_lr_multiplier, "best_win_ratio": tp.best_win_ratio,
+                          "lr_multiplier": tp.lr_multiplier, "max_lr_multiplier": tp.max_lr_multiplier,
+                          "zero_head_biases": tp.zeroed_head_biases,
+                          "reference_controller": tp.max_lr_multiplier == 10.0 and not tp.zeroed_head_biases,
+                          "best_win_ratio": tp.best_win_ratio,
                           "evaluations_batch_playouts_win_ratio": tp.eval_history,
                           "timer": "starts after one optimiser step on a scratch net (library initialisation), ends after the last update"}))
     if world > 1:

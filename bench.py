@@ -2,8 +2,12 @@
 """Self-play throughput of the HIP engine: completed 8x8 / 5-in-row / n_playout=400 games per
 second with 1024 games in flight per GPU, random-init net, synthetic start positions.
 
-    python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+With N > 1 and no launcher (no RANK in the environment) this program starts its N rank processes
+itself -- fresh interpreters, one per GPU, started before anything here has touched the GPU --
+relays rank 0's line and fails if any rank fails.  Under a launcher --gpus must equal WORLD_SIZE.
 
 A step is one move for every game slot: n_playout playouts per game inside one launch of the
 fused search kernel (select / leaf CNN / expand / backup), then sampling the move, recording
@@ -166,9 +170,86 @@ def visit_l1_vs_cpu(az, az_oracle, n, k, n_playout, params, params_np, samples, 
             "note": "fresh-root searches from positions of the timed run's games; CPU side = oracle tree + its float64 net"}
 
 
+def _free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def launch_ranks(n, argv, child=None, timeout=1500.0, env=None):
+    """Start n rank processes (RANK = LOCAL_RANK = 0..n-1, WORLD_SIZE = n, rendezvous on
+    127.0.0.1 at a free port), wait for all of them and return (exit code, rank 0's JSON line or
+    None).  `child` is the command every rank runs (default: this program in a fresh interpreter)
+    followed by argv.  Rank 0's stdout is captured; the other ranks' stdout goes to stderr, so the
+    caller's stdout carries nothing but the one line it prints itself.  The first rank that fails
+    (or the time limit) ends the others: exactly the processes started here, by their PIDs.
+    The caller must not have initialised the GPU: children are separate processes, never an exec
+    of this one."""
+    import subprocess
+    import threading
+    child = list(child) if child else [sys.executable, "-u", os.path.abspath(__file__)]
+    base = dict(os.environ if env is None else env)
+    base.update({"WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n), "MASTER_ADDR": "127.0.0.1",
+                 "MASTER_PORT": str(_free_port())})
+    procs = []
+    for r in range(n):
+        e = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen(child + list(argv), env=e, stdout=subprocess.PIPE if r == 0 else sys.stderr,
+                                      stderr=sys.stderr, text=(r == 0) or None))
+    lines = []
+    reader = threading.Thread(target=lambda: lines.extend(procs[0].stdout), daemon=True)
+    reader.start()
+    deadline = time.time() + timeout
+    rc = 0
+    pending = set(range(n))
+    while pending and rc == 0:
+        for r in sorted(pending):
+            code = procs[r].poll()
+            if code is not None:
+                pending.discard(r)
+                if code != 0:
+                    print("bench.py: rank %d of %d exited with code %d" % (r, n, code), file=sys.stderr)
+                    rc = code if 0 < code < 256 else 1
+        if pending and rc == 0:
+            if time.time() > deadline:
+                print("bench.py: ranks %s still running after %.0f s" % (sorted(pending), timeout), file=sys.stderr)
+                rc = 124
+            else:
+                time.sleep(0.05)
+    for r in sorted(pending):                       # a failure or the time limit: end what was started here
+        procs[r].terminate()
+    for r in sorted(pending):
+        try:
+            procs[r].wait(timeout=20)
+        except subprocess.TimeoutExpired:
+            procs[r].kill()
+            procs[r].wait()
+    reader.join(timeout=10)
+    line = None
+    for text in lines:
+        text = text.strip()
+        if text.startswith("{"):
+            try:
+                json.loads(text)
+                line = text
+            except ValueError:
+                pass
+        elif text:
+            print(text, file=sys.stderr)            # anything else a rank wrote to stdout is not the result
+    if rc == 0 and line is None:
+        print("bench.py: rank 0 printed no JSON line", file=sys.stderr)
+        rc = 1
+    return rc, line
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None,
+                    help="ranks = GPUs of the run (default: WORLD_SIZE under a launcher, else 1); with N > 1 and no "
+                         "launcher this program starts the N rank processes itself")
+    ap.add_argument("--launch-timeout", type=float, default=1500.0,
+                    help="seconds the self-started ranks of --gpus N may take before they are ended")
     ap.add_argument("--steps", type=int, default=96)
     ap.add_argument("--warmup", type=int, default=64)
     ap.add_argument("--games", type=int, default=1024, help="game slots per GPU")
@@ -189,12 +270,31 @@ def main():
                     help="conv arithmetic: split-f16 MFMA (three products, f32 accumulate) or f32-input MFMA")
     args = ap.parse_args()
 
+    under_launcher = "RANK" in os.environ
+    env_world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus is None:
+        args.gpus = env_world if under_launcher else 1
+    if args.gpus < 1:
+        ap.error("--gpus must be at least 1")
+    if under_launcher and args.gpus != env_world:
+        print("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, env_world), file=sys.stderr)
+        sys.exit(2)
+    if args.gpus > 1 and not under_launcher:
+        # no launcher: be one.  Nothing in this process has touched the GPU (torch is not even imported).
+        rc, line = launch_ranks(args.gpus, sys.argv[1:], timeout=args.launch_timeout)
+        if line is not None and rc == 0:
+            print(line)
+        sys.exit(rc)
+
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
     local_rank = 0 if args.rehearse_on_one_gpu else int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    use_dist = world > 1 or "RANK" in os.environ
+    world = env_world if under_launcher else 1
+    use_dist = under_launcher
+    if not args.rehearse_on_one_gpu and local_rank >= torch.cuda.device_count():
+        print("bench.py: rank %d needs GPU %d, this machine shows %d" % (rank, local_rank, torch.cuda.device_count()), file=sys.stderr)
+        sys.exit(3)
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
@@ -300,13 +400,17 @@ def main():
     launches, kernel_ms, evals = eng.profile()
     host = eng.host_timing()
 
-    stats = torch.tensor([dt, games, plies, evals, kernel_ms, launches, all_games, preroll], dtype=torch.float64,
+    stats = torch.tensor([dt, games, plies, evals, kernel_ms, launches, all_games, preroll, 1.0], dtype=torch.float64,
                          device="cpu" if args.rehearse_on_one_gpu else dev)
+    ranks_seen, dt_min, dt_max = 1, dt, dt
     if use_dist:
         mx = stats.clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         sm = stats.clone()
         dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+        mn = stats.clone()
+        dist.all_reduce(mn, op=dist.ReduceOp.MIN)
+        ranks_seen, dt_min, dt_max = int(round(float(sm[8]))), float(mn[0]), float(mx[0])   # a one from every rank of the group
         dt = float(mx[0])
         games, plies, evals, all_games = float(sm[1]), float(sm[2]), float(sm[3]), float(sm[6])
         kernel_ms, launches = float(sm[4]) / world, float(sm[5]) / world
@@ -320,8 +424,11 @@ def main():
         traffic, traffic_src = pmc_traffic(args.cnn, n, args.playouts, args.games)
         out = {
             "metric": "completed self-play games/sec, %dx%d board n_playout=%d" % (n, n, args.playouts),
-            "value": games / dt, "unit": "games/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "value": games / dt, "unit": "games/s", "n_gpus": world, "ranks_seen": ranks_seen, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "ms_per_step_rank_min_max": [dt_min / args.steps * 1e3, dt_max / args.steps * 1e3],
+            "backend": ("gloo" if args.rehearse_on_one_gpu else "nccl (RCCL)") if use_dist else None,
+            "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
             "dtype": "f16x3 (f32 operands split into two halves, three f16 MFMAs per product, f32 accumulate; tree in f64)" if args.cnn == "f16x3" else "f32",
             "data": "synthetic" + (" (REHEARSAL: all ranks share GPU 0, exchange over gloo -- not a measurement)" if args.rehearse_on_one_gpu else ""),

@@ -218,13 +218,15 @@ int azg_board_step_batch(azg_handle *h, int n, uint64_t *stones, int32_t *ply,
                          int32_t *last_move, const int32_t *moves, const int32_t *player,
                          uint8_t *ended, int8_t *winner, float *planes);
 
-/* azg_board_step_batch for callers that cannot allocate device memory (code under HIP graph
- * capture, tight serving loops, harnesses that forbid hipMalloc).  It has no counterpart in the
- * reference.  Same arguments, results and errors as azg_board_step_batch, but staging, the
- * illegal-move flag and the outputs live in a fixed 4.3 MB array that every GPU running this
- * library holds until the process ends, and the call makes no hipMalloc / hipFree of any kind.
- * At most 1024 boards per call (AZG_EINVAL beyond that).  All calls on one GPU share that array:
- * calls that overlap in time on one GPU race, whatever handle they use. */
+/* azg_board_step_batch for callers that may not allocate device memory (tight serving loops,
+ * harnesses that forbid hipMalloc).  It has no counterpart in the reference.  Same arguments,
+ * results and errors as azg_board_step_batch, but staging, the illegal-move flag and the outputs
+ * live in a fixed 4.3 MB array that every GPU running this library holds until the process ends,
+ * and the call makes no hipMalloc / hipFree of any kind.  Like azg_board_step_batch it takes HOST
+ * pointers, runs on the handle's own stream and is synchronous (it ends with a stream
+ * synchronisation), so it cannot be recorded into a caller's HIP graph.  At most 1024 boards per
+ * call (AZG_EINVAL beyond that).  All calls on one GPU share that array: calls that overlap in
+ * time on one GPU race, whatever handle they use. */
 int azg_board_step_batch_static(azg_handle *h, int n, uint64_t *stones, int32_t *ply,
                                 int32_t *last_move, const int32_t *moves, const int32_t *player,
                                 uint8_t *ended, int8_t *winner, float *planes);
@@ -259,6 +261,16 @@ int azg_reroot_stats(azg_handle *h, int64_t *in_place, int64_t *compacted);
  * mcts_alphaZero.py:236-240, generated on host threads while a search runs): summed wall
  * milliseconds and number of move steps since the last call.  Resets the counters. */
 int azg_host_timing(azg_handle *h, double *noise_ms, int64_t *noise_steps);
+
+/* Diagnostics of the per-CU matrix gate (no counterpart in the reference).  Two search workgroups
+ * share a compute unit; a word per CU in a device-wide table makes their dense convolution phases
+ * alternate.  The gate is advisory (bounded wait, results never depend on it); azg_create and
+ * azg_selfplay_begin clear the table.  azg_gate_stats: waits that ran out since the process started
+ * on this GPU (a number > 0 means launches ran part of their time without the alternation: slower,
+ * not wrong), and the table words that are set right now.  azg_gate_poke stores `value` in every
+ * word (tests: a table left dirty by a launch that died). */
+int azg_gate_stats(azg_handle *h, int64_t *giveups, int64_t *words_set);
+int azg_gate_poke(azg_handle *h, int value);
 
 /* The handle's HIP stream (hipStream_t), for callers that record their own events. */
 void *azg_stream(azg_handle *h);

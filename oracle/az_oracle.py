@@ -307,8 +307,9 @@ def pure_get_move(board, c_puct, n_playout, rng):
 
 def equi_data(play_data, board_height, board_width):
     """TrainPipeline.get_equi_data (train.py:116-135) restated with the same numpy calls.
-    train.py itself cannot be imported here (it imports the Keras net at module level), so this
-    restatement is pinned only by reading the reference: parity unpinned by a reference run."""
+    train.py itself cannot be imported (it imports the Keras net at module level); the fixture
+    tests/golden/g6_equi.npz was produced by the reference's own method body, compiled out of
+    train.py's syntax tree, and tests/test_oracle.py checks this restatement against it."""
     extend_data = []
     for state, mcts_prob, winner in play_data:
         for i in [1, 2, 3, 4]:

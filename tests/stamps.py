@@ -7,6 +7,17 @@ import helpers
 import alphazero_gomoku_amd as az
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+# A stamp build carries a branch of one thread behind the matrix loops; whether THIS build still
+# computes the exact searches is checked first and printed with the figures (tests/hazard_check.py:
+# identical searches against the evaluation kernel and the oracle's float64 net).
+import hazard_check
+_ex = hazard_check.check(n, 256, 8)
+print("exactness of this build: root priors differ from the evaluation kernel in %d of %d slots, trees differ in %d, "
+      "evaluation kernel vs oracle net %.1e, search vs oracle net %.1e -> %s"
+      % (_ex["root_priors_differ_from_eval_kernel"], _ex["slots"], _ex["trees_differ_from_the_most_common"],
+         _ex["eval_kernel_max_abs_err_vs_oracle_net"], _ex["search_root_priors_max_abs_err_vs_oracle_net"],
+         "EXACT" if _ex["root_priors_differ_from_eval_kernel"] == 0 and _ex["trees_differ_from_the_most_common"] == 0
+         and _ex["eval_kernel_max_abs_err_vs_oracle_net"] < 1e-5 else "NOT EXACT: the figures below are of searches that differ from the shipped ones"))
 eng = az.SelfPlayEngine(n, 5, int(os.environ.get("PLAYOUTS", 400 if n == 8 else 200)), B, cnn_mode=int(os.environ.get("CNN_MODE", "0")))
 if os.environ.get("MODEL"):              # a trained net instead of random weights: deep, narrow trees
     from alphazero_gomoku_amd.net import PolicyValueNet

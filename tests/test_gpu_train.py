@@ -210,6 +210,94 @@ def test_callback_player_reproduces_reference_game(az, oracle):
     assert calls[0] > 0.9 * g["n_playout"] * len(g["moves"]) - 400
 
 
+def test_callback_values_outside_the_unit_range(az, oracle):
+    """azg_playout_begin / azg_playout_end accept any finite value and priors of any size or sign
+    (mcts_alphaZero.py:98-103 puts no bound on what policy_value_fn returns): with values of +-50 and
+    signed, unnormalised priors the tree must still be the oracle's, visit for visit and Q for Q --
+    the descent that serves these calls takes the double-precision pass at every level."""
+    n, k, npo = 6, 4, 300
+    S = n * n
+
+    def fn(cells_key):
+        rs = np.random.RandomState(cells_key % (2 ** 31))
+        pri = (rs.rand(S) * 40.0 - 20.0).astype(np.float32)
+        # many exact ties and near-ties between children, far from the unit range
+        pri[rs.rand(S) < 0.5] = np.float32(7.25)
+        val = float(np.float32(rs.rand() * 100.0 - 50.0))
+        return pri, val
+
+    def key_of(s1, s2, cur):
+        return (s1 * 1000003 + s2 * 7919 + cur) % (2 ** 61 - 1)
+
+    eng = az.SelfPlayEngine(n, k, npo, 1, prior_mode=az.PRIOR_HASH)
+    eng.reset_games(seeds=np.array([5], dtype=np.uint32))
+    for _ in range(npo):
+        s1, s2, ply, last, cur, term = eng.playout_begin(0)
+        if term:
+            eng.playout_end(None, 0.0, 0)
+        else:
+            pri, val = fn(key_of(s1, s2, cur))
+            eng.playout_end(pri, val, 0)
+    visits, q, p, rn = eng.root_stats()
+    eng.close()
+
+    def policy(b):
+        s1 = s2 = 0
+        for c in range(S):
+            if b.cell[c] == 1:
+                s1 |= 1 << c
+            elif b.cell[c] == 2:
+                s2 |= 1 << c
+        pri, val = fn(key_of(s1, s2, b.current_player))
+        return [float(x) for x in pri], val
+    ob = oracle.OracleBoard(n, n, k)
+    ob.init_board()
+    t = oracle.OracleMCTS(policy, c_puct=5, n_playout=npo)
+    acts, ovis, oq, op, _ = t.get_move_probs(ob, temp=1.0)
+    assert int(rn[0]) == npo and np.array_equal(visits[0][acts], ovis)
+    assert np.array_equal(q[0][acts], oq) and np.array_equal(p[0][acts], op)
+
+
+def test_matrix_gate_table_is_cleared_and_give_ups_are_counted(az):
+    """The per-CU matrix gate only schedules: with every gate word left set (as a launch that died
+    inside a gated span would leave them) a search gives the same tree, the waits that ran out show
+    up in azg_gate_stats, and the next azg_create / azg_selfplay_begin start from a clean table."""
+    n, k, npo = 8, 5, 24
+    params = helpers.make_params(n, seed=108, scale=2.0)
+    seeds = np.arange(4, dtype=np.uint32) + 11
+
+    def run(poke):
+        eng = az.SelfPlayEngine(n, k, npo, 4)
+        eng.set_weights(params)
+        eng.reset_games(seeds=seeds)
+        if poke:
+            eng.gate_poke(1)
+            assert eng.gate_stats()[1] == 4096
+        g0 = eng.gate_stats()[0]
+        eng.search()
+        out = eng.root_stats()
+        g1 = eng.gate_stats()[0]
+        eng.close()
+        return out, g1 - g0
+    clean, _ = run(False)
+    dirty, gave_up = run(True)
+    for a, b in zip(clean, dirty):
+        assert np.array_equal(a, b)
+    assert gave_up > 0
+    eng = az.SelfPlayEngine(n, k, npo, 4)
+    eng.gate_poke(1)
+    eng2 = az.SelfPlayEngine(n, k, npo, 4)                   # azg_create clears the table of the GPU
+    assert eng2.gate_stats()[1] == 0
+    eng2.close()
+    eng.gate_poke(1)
+    eng.set_weights(params)
+    eng.selfplay_begin(1.0, 0, 0, 1, None)                   # and so does azg_selfplay_begin
+    eng.selfplay_step()
+    eng.selfplay_fetch(0)
+    eng.selfplay_end()
+    eng.close()
+
+
 def test_c4_full_size_slots_against_oracle(az, oracle):
     """Configuration C4 at full size (512 games of 15x15, 5 in a row, 800 playouts, CNN): slots 0,
     255 and 511 over three plies against the oracle's tree fed the GPU CNN's own outputs -- every

@@ -294,6 +294,17 @@ def test_lr_multiplier_ceiling():
         assert abs(tp.lr_multiplier - top) < 1e-12, (ceiling, tp.lr_multiplier)
 
 
+def test_controller_defaults_are_the_references_with_one_game_per_batch():
+    """play_batch_size 1 (the reference's configuration): ceiling 10 (train.py:199) and an untouched
+    initialisation; batched play deviates on purpose and says so; explicit arguments win."""
+    from alphazero_gomoku_amd.train import TrainPipeline
+    assert TrainPipeline.controller_defaults(1) == (10.0, False)
+    assert TrainPipeline.controller_defaults(0) == (10.0, False)
+    assert TrainPipeline.controller_defaults(1024) == (1.0, True)
+    assert TrainPipeline.controller_defaults(1024, max_lr_multiplier=10, zero_head_biases=False) == (10.0, False)
+    assert TrainPipeline.controller_defaults(1, max_lr_multiplier=2, zero_head_biases=True) == (2.0, True)
+
+
 def test_train_step_matches_reference_on_cpu():
     """train_step_tensors (the arithmetic of PolicyValueNet.train_step) on the CPU against the
     reference's PolicyValueNet.train_step (policy_value_net_pytorch.py:117-148, run by
@@ -408,3 +419,74 @@ def test_pickled_model_files_are_read_without_unpickling(tmp_path):
     for name in ("cut.model", "text.model"):
         with pytest.raises(ValueError):
             model_files.read_pickled_arrays(tmp_path / name)
+
+
+# ---- bench.py --gpus N without a launcher -----------------------------------------------------------
+_STUB_RANK = r'''
+import json, os, sys, time
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+mode = sys.argv[1]
+print("noise from rank %d" % rank)                      # must never reach the caller's stdout as the result
+if mode == "fail" and rank == 1:
+    sys.exit(7)
+if mode == "hang" and rank == 1:
+    time.sleep(600)
+if mode == "fail" and rank == 0:
+    time.sleep(600)                                      # must be ended by the launcher, not waited for
+if rank == 0:
+    print(json.dumps({"n_gpus": world, "local_rank": os.environ["LOCAL_RANK"], "addr": os.environ["MASTER_ADDR"],
+                      "port": int(os.environ["MASTER_PORT"]), "argv": sys.argv[2:]}))
+'''
+
+
+def _bench_module():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_bench_starts_its_own_ranks(tmp_path, capfd):
+    """`python bench.py --gpus N` with no launcher starts N rank processes with the rendezvous
+    variables set, relays rank 0's JSON line alone, and fails when a rank fails or hangs."""
+    import json
+    import sys
+    import time
+    bench = _bench_module()
+    stub = tmp_path / "stub_rank.py"
+    stub.write_text(_STUB_RANK)
+    rc, line = bench.launch_ranks(3, ["ok", "--steps", "3"], child=[sys.executable, str(stub)], timeout=60)
+    assert rc == 0
+    rec = json.loads(line)
+    assert rec["n_gpus"] == 3 and rec["local_rank"] == "0" and rec["addr"] == "127.0.0.1" and rec["argv"] == ["--steps", "3"]
+    assert rec["port"] > 0
+    t0 = time.time()
+    rc, line = bench.launch_ranks(2, ["fail"], child=[sys.executable, str(stub)], timeout=60)
+    assert rc == 7 and line is None and time.time() - t0 < 30          # rank 0 was ended, not waited for
+    t0 = time.time()
+    rc, line = bench.launch_ranks(2, ["hang"], child=[sys.executable, str(stub)], timeout=2)
+    assert rc == 124 and time.time() - t0 < 30
+    capfd.readouterr()
+
+
+def test_bench_refuses_a_gpu_count_the_launcher_did_not_start():
+    """Under a launcher --gpus must equal WORLD_SIZE: a mismatch is an error, never a line for fewer ranks."""
+    import subprocess
+    import sys
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8"], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 2 and "WORLD_SIZE=2" in r.stderr and r.stdout.strip() == ""
+
+
+def test_bench_with_more_gpus_than_the_machine_has_fails_loudly():
+    """No launcher, --gpus 2 on a machine without two GPUs: the ranks are started, find no device and
+    the whole run exits non-zero without a result line."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("two GPUs present")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--launch-timeout", "240"], capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and r.stdout.strip() == "" and "needs GPU" in r.stderr
