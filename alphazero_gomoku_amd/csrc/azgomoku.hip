@@ -19,6 +19,16 @@
 
 #include "azg_kernels.hpp"
 #include "azg_pure.hpp"
+#ifndef AZG_TRAIN_BN3
+#define AZG_TRAIN_BN3 128     // columns per workgroup of conv3's forward GEMM (64: twice the workgroups)
+#endif
+#ifndef AZG_TRAIN_BD3
+#define AZG_TRAIN_BD3 64      // columns per workgroup of conv3's backward-data GEMM (64 columns in all)
+#endif
+#ifndef AZG_TRAIN_WCAP
+#define AZG_TRAIN_WCAP 64     // most splits of the batch in the weight-gradient GEMMs of conv2 / conv3
+#endif
+#include "azg_train.hpp"
 #include "np_legacy_rng.hpp"
 
 using namespace azg;
@@ -190,6 +200,20 @@ struct azg_handle {
     // grow-on-demand device scratch
     void *scratch[48] = {nullptr};
     size_t scratch_sz[48] = {0};
+    // training step (azg_train_*): activations, gradients and partial sums of one mini-batch
+    struct TrainWs {
+        int cap_n = 0;                           // samples the buffers hold
+        char *block = nullptr;                   // one allocation, carved up below
+        hipStream_t stream = nullptr;            // the training kernels' own stream (never behind a search in flight)
+        float *x4 = nullptr, *a[3] = {nullptr}, *dz[3] = {nullptr}, *hp = nullptr, *hv = nullptr, *dh8 = nullptr;
+        float *dlogit = nullptr, *dh1 = nullptr, *g2 = nullptr, *lossparts = nullptr, *lossout = nullptr;
+        TrainImages im{};
+        float *wpart[3] = {nullptr}, *bpart[3] = {nullptr}, *hpart = nullptr, *hbpart = nullptr;
+        float *ppart = nullptr, *pbpart = nullptr, *vpart = nullptr, *vbpart = nullptr, *g2part = nullptr;
+        int wsplits[3] = {0}, wrows[3] = {0}, hsplits = 0, hrows = 0, fsplits = 0, frows = 0, gsplits = 0, grows = 0;
+        const float *checked[16] = {nullptr};    // parameter pointers already seen to be device memory
+        float *h_loss = nullptr;                 // pinned [2]
+    } tw;
     // profiling
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
     size_t ev_pending = 0;
@@ -453,6 +477,9 @@ extern "C" void azg_destroy(azg_handle *h)
     if (h->h_moves) (void)hipHostFree(h->h_moves);
     if (h->h_mirror) (void)hipHostFree(h->h_mirror);
     if (h->h_static_bad) (void)hipHostFree(h->h_static_bad);
+    if (h->tw.block) (void)hipFree(h->tw.block);
+    if (h->tw.h_loss) (void)hipHostFree(h->tw.h_loss);
+    if (h->tw.stream) (void)hipStreamDestroy(h->tw.stream);
     if (h->sp.h_map) (void)hipHostFree(h->sp.h_map);
     if (h->sp.h_ids) (void)hipHostFree(h->sp.h_ids);
     if (h->sp.ev_mirror) (void)hipEventDestroy(h->sp.ev_mirror);
@@ -1587,6 +1614,313 @@ extern "C" int azg_equi_data(azg_handle *h, int n, const float *states, const do
     }
     HIPCHK(h, hipStreamSynchronize(cs));
     return AZG_OK;
+}
+
+
+// ---------------------------------------------------------------- training step
+// PolicyValueNet.train_step (policy_value_net_pytorch.py:117-148) and the forward pass of
+// PolicyValueNet.policy_value (:80-94) on a mini-batch, in float32 (kernels: azg_train.hpp).
+static const int kTrainCin[3] = {4, 32, 64}, kTrainCout[3] = {32, 64, 128};
+
+// rows per split and number of splits of a reduction over M rows that should give about `want` workgroups
+static void split_rows(int M, int want, int cap, int *rows, int *splits)
+{
+    want = std::max(1, std::min(want, cap));
+    int r = (M + want - 1) / want;
+    r = std::max(TKC, (r + TKC - 1) / TKC * TKC);
+    *rows = r;
+    *splits = (M + r - 1) / r;
+}
+
+static int train_prepare(azg_handle *h, int n)
+{
+    auto &w = h->tw;
+    const int S = h->st.S;
+    if (!w.stream) HIPCHK(h, hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking));
+    if (!w.h_loss) HIPCHK(h, hipHostMalloc((void **)&w.h_loss, 16));
+    const int M = n * S;
+    for (int l = 0; l < 3; l++) {
+        const int tiles = ((9 * kTrainCin[l] + TBM - 1) / TBM);
+        split_rows(M, (AZG_TRAIN_WCAP * 4) / tiles, l == 0 ? 256 : AZG_TRAIN_WCAP, &w.wrows[l], &w.wsplits[l]);
+    }
+    split_rows(M, 256, 256, &w.hrows, &w.hsplits);
+    split_rows(n, 8, 8, &w.frows, &w.fsplits);
+    split_rows(n, 64, 64, &w.grows, &w.gsplits);
+    if (n <= w.cap_n) return AZG_OK;
+    if (w.block) HIPCHK(h, hipFree(w.block));
+    w.block = nullptr;
+    w.cap_n = 0;
+    size_t off = 0;
+    auto take = [&](size_t floats) { const size_t at = off; off += (floats * 4 + 255) / 256 * 256; return at; };
+    const size_t Mz = (size_t)M;
+    const int Sp = (S + 3) & ~3, ldhv = (2 * S + 3) & ~3;
+    const size_t o_x4 = take(Mz * 4), o_a0 = take(Mz * 32), o_a1 = take(Mz * 64), o_a2 = take(Mz * 128);
+    const size_t o_d0 = take(Mz * 32), o_d1 = take(Mz * 64), o_d2 = take(Mz * 128);
+    const size_t o_hp = take((size_t)n * 4 * S), o_hv = take((size_t)n * ldhv), o_dh8 = take(Mz * 8);
+    const size_t o_dl = take((size_t)n * Sp), o_dh1 = take((size_t)n * 64), o_g2 = take((size_t)n * 128);
+    const size_t o_lp = take((size_t)n * 3), o_lo = take(4);
+    size_t o_wf[3], o_wd[3], o_wp[3], o_bp[3];
+    for (int l = 0; l < 3; l++) {
+        o_wf[l] = take((size_t)kTrainCout[l] * kTrainCin[l] * 9);
+        o_wd[l] = take((size_t)kTrainCout[l] * kTrainCin[l] * 9);
+        o_wp[l] = take((size_t)(l == 0 ? 256 : AZG_TRAIN_WCAP) * 9 * kTrainCin[l] * kTrainCout[l]);
+        o_bp[l] = take((size_t)(l == 0 ? 256 : AZG_TRAIN_WCAP) * kTrainCout[l]);
+    }
+    const size_t o_wh = take(32 * 128), o_bh = take(8), o_hpt = take((size_t)256 * 128 * 8), o_hbp = take(256 * 8);
+    const size_t o_pp = take((size_t)8 * 4 * S * S), o_pbp = take((size_t)8 * S), o_vp = take((size_t)8 * 2 * S * 64), o_vbp = take(8 * 64);
+    const size_t o_g2p = take(64 * 128);
+    HIPCHK(h, hipMalloc((void **)&w.block, off));
+    HIPCHK(h, hipMemsetAsync(w.block, 0, off, w.stream));      // the padding columns of hv stay zero for good
+    char *b = w.block;
+    auto at = [&](size_t o) { return reinterpret_cast<float *>(b + o); };
+    w.x4 = at(o_x4); w.a[0] = at(o_a0); w.a[1] = at(o_a1); w.a[2] = at(o_a2);
+    w.dz[0] = at(o_d0); w.dz[1] = at(o_d1); w.dz[2] = at(o_d2);
+    w.hp = at(o_hp); w.hv = at(o_hv); w.dh8 = at(o_dh8); w.dlogit = at(o_dl); w.dh1 = at(o_dh1); w.g2 = at(o_g2);
+    w.lossparts = at(o_lp); w.lossout = at(o_lo);
+    for (int l = 0; l < 3; l++) { w.im.wf[l] = at(o_wf[l]); w.im.wd[l] = at(o_wd[l]); w.wpart[l] = at(o_wp[l]); w.bpart[l] = at(o_bp[l]); }
+    w.im.wh = at(o_wh); w.im.bh = at(o_bh); w.hpart = at(o_hpt); w.hbpart = at(o_hbp);
+    w.ppart = at(o_pp); w.pbpart = at(o_pbp); w.vpart = at(o_vp); w.vbpart = at(o_vbp); w.g2part = at(o_g2p);
+    w.cap_n = n;
+    return AZG_OK;
+}
+
+// The 16 parameter pointers of a net do not change between calls: they are looked at once.
+static int train_check_ptrs(azg_handle *h, const float *const params[16])
+{
+    if (!params) return fail(h, AZG_EINVAL, "null argument");
+    bool same = true;
+    for (int i = 0; i < 16; i++) same = same && params[i] == h->tw.checked[i];
+    if (same && params[0]) return AZG_OK;
+    for (int i = 0; i < 16; i++)
+        if (!params[i] || !is_device_ptr(params[i])) return fail(h, AZG_EINVAL, "parameter tensor %d must be a device pointer", i);
+    for (int i = 0; i < 16; i++) h->tw.checked[i] = params[i];
+    return AZG_OK;
+}
+
+// Dynamic LDS that a training GEMM asks for on top of its tiles, only to bound how many of its
+// workgroups share a CU (AZG_TRAIN_LDSPAD in the environment, bytes; experiment knob).
+static size_t train_lds_pad()
+{
+    static const size_t pad = [] { const char *e = getenv("AZG_TRAIN_LDSPAD"); return e ? (size_t)atol(e) : (size_t)0; }();
+    return pad;
+}
+template <class K>
+static void train_allow_lds(K kernel)
+{
+    if (train_lds_pad()) (void)hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)train_lds_pad());
+}
+
+template <int BN, int MODE>
+static void launch_conv_gemm(hipStream_t s, const ConvGemmArgs &a)
+{
+    static const bool once = (train_allow_lds(conv_gemm_kernel<BN, MODE>), true);
+    (void)once;
+    hipLaunchKernelGGL((conv_gemm_kernel<BN, MODE>), dim3((a.M + TBM - 1) / TBM, (a.N + BN - 1) / BN), dim3(256), train_lds_pad(), s, a);
+}
+
+// forward pass of the batch already at w.x4 (channels-last) up to the head outputs hp / hv
+static void train_forward_convs(azg_handle *h, int n, const TrainParams &P)
+{
+    auto &w = h->tw;
+    const int S = h->st.S, N = h->st.N, M = n * S;
+    hipStream_t s = w.stream;
+    hipLaunchKernelGGL(train_pack_kernel, dim3((kTrainPackThreads + 255) / 256), dim3(256), 0, s, P, w.im);
+    ConvGemmArgs a{};
+    a.M = M; a.S = S; a.Nb = N; a.taps = 9;
+    a.src = w.x4; a.Cs = 4; a.K = 36; a.w = w.im.wf[0]; a.bias = P.p[1]; a.out = w.a[0]; a.N = 32; a.ldo = 32;
+    launch_conv_gemm<32, 0>(s, a);
+    a.src = w.a[0]; a.Cs = 32; a.K = 288; a.w = w.im.wf[1]; a.bias = P.p[3]; a.out = w.a[1]; a.N = 64; a.ldo = 64;
+    launch_conv_gemm<64, 0>(s, a);
+    a.src = w.a[1]; a.Cs = 64; a.K = 576; a.w = w.im.wf[2]; a.bias = P.p[5]; a.out = w.a[2]; a.N = 128; a.ldo = 128;
+    launch_conv_gemm<AZG_TRAIN_BN3, 0>(s, a);
+    a.src = w.a[2]; a.Cs = 128; a.K = 128; a.taps = 1; a.w = w.im.wh; a.bias = w.im.bh; a.out = w.hp; a.out2 = w.hv; a.N = 32;
+    a.ldo = (2 * S + 3) & ~3;
+    launch_conv_gemm<32, 2>(s, a);
+}
+
+static FcArgs train_fc_args(azg_handle *h, int n, const TrainParams &P)
+{
+    auto &w = h->tw;
+    FcArgs f{};
+    f.hp = w.hp; f.hv = w.hv; f.wp = P.p[8]; f.bp = P.p[9]; f.wv1 = P.p[12]; f.bv1 = P.p[13]; f.wv2 = P.p[14]; f.bv2 = P.p[15];
+    f.dlogit = w.dlogit; f.dh1 = w.dh1; f.g2 = w.g2; f.dh8 = w.dh8; f.lossparts = w.lossparts;
+    f.n = n; f.S = h->st.S; f.ldhv = (2 * h->st.S + 3) & ~3;
+    return f;
+}
+
+extern "C" int azg_train_forward(azg_handle *h, int n, const float *states, const float *const params[16], float *probs,
+                                 float *values)
+{
+    if (!h || n < 0 || !states || !probs || !values) return fail(h, AZG_EINVAL, "null argument");
+    if (n == 0) return AZG_OK;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    int rc = train_check_ptrs(h, params);
+    if (rc) return rc;
+    if (!is_device_ptr(states) || !is_device_ptr(probs)) return fail(h, AZG_EINVAL, "azg_train_forward takes device pointers");
+    if ((rc = train_prepare(h, n))) return rc;
+    auto &w = h->tw;
+    TrainParams P;
+    for (int i = 0; i < 16; i++) P.p[i] = const_cast<float *>(params[i]);
+    const int M = n * h->st.S;
+    hipLaunchKernelGGL(planes_to_rows_kernel, dim3((M + 255) / 256), dim3(256), 0, w.stream, states, n, h->st.S, w.x4);
+    train_forward_convs(h, n, P);
+    FcArgs f = train_fc_args(h, n, P);
+    f.probs = probs; f.values = values;
+    hipLaunchKernelGGL(fc_sample_kernel, dim3(n), dim3(256), 0, w.stream, f);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipStreamSynchronize(w.stream));
+    return AZG_OK;
+}
+
+// forward + backward of one mini-batch, enqueued on the training stream (no synchronisation)
+static int train_backward_enqueue(azg_handle *h, int n, const float *states, const float *mcts_probs, const float *winners,
+                                  const TrainParams &P, float *grads)
+{
+    auto &w = h->tw;
+    hipStream_t s = w.stream;
+    const int S = h->st.S, N = h->st.N, M = n * S;
+    hipLaunchKernelGGL(planes_to_rows_kernel, dim3((M + 255) / 256), dim3(256), 0, s, states, n, S, w.x4);
+    train_forward_convs(h, n, P);
+    FcArgs f = train_fc_args(h, n, P);
+    f.pi = mcts_probs; f.z = winners;
+    hipLaunchKernelGGL(fc_sample_kernel, dim3(n), dim3(256), 0, s, f);
+    hipLaunchKernelGGL(loss_kernel, dim3(1), dim3(256), 0, s, (const float *)w.lossparts, n, w.lossout);
+    // fully connected layers: weight gradients as [input][output] partial sums, bias gradients with them
+    {
+        WgradArgs g{};
+        g.taps = 1; g.M = n; g.S = 1; g.Nb = 1; g.rows_per_split = w.frows;
+        g.src = w.hp; g.Cs = 4 * S; g.I = 4 * S; g.dz = w.dlogit; g.ldz = (S + 3) & ~3; g.J = S; g.part = w.ppart; g.bpart = w.pbpart;
+        hipLaunchKernelGGL((wgrad_gemm_kernel<64>), dim3((g.I + TBM - 1) / TBM, (g.J + 63) / 64, w.fsplits), dim3(256), 0, s, g);
+        g.src = w.hv; g.Cs = (2 * S + 3) & ~3; g.I = 2 * S; g.dz = w.dh1; g.ldz = 64; g.J = 64; g.part = w.vpart; g.bpart = w.vbpart;
+        hipLaunchKernelGGL((wgrad_gemm_kernel<64>), dim3((g.I + TBM - 1) / TBM, 1, w.fsplits), dim3(256), 0, s, g);
+        hipLaunchKernelGGL(colsum_kernel, dim3(w.gsplits), dim3(256), 0, s, (const float *)w.g2, n, 128, 128, w.grows, w.g2part);
+    }
+    // heads: weight and bias gradients (partials), gradient at conv3's pre-activation
+    {
+        WgradArgs g{};
+        g.src = w.a[2]; g.Cs = 128; g.taps = 1; g.I = 128; g.dz = w.dh8; g.ldz = 8; g.J = 8; g.part = w.hpart; g.bpart = w.hbpart;
+        g.M = M; g.S = S; g.Nb = N; g.rows_per_split = w.hrows;
+        hipLaunchKernelGGL((wgrad_gemm_kernel<32>), dim3(1, 1, w.hsplits), dim3(256), 0, s, g);
+        hipLaunchKernelGGL(head_backward_kernel, dim3((M * 32 + 255) / 256), dim3(256), 0, s, (const float *)w.dh8,
+                           (const float *)w.im.wh, (const float *)w.a[2], M, w.dz[2]);
+    }
+    // the three 3x3 layers, last to first: weight / bias gradients of layer l, then the gradient at layer l-1
+    for (int l = 2; l >= 0; l--) {
+        WgradArgs g{};
+        g.src = l == 0 ? w.x4 : w.a[l - 1]; g.Cs = kTrainCin[l]; g.taps = 9; g.I = 9 * kTrainCin[l];
+        g.dz = w.dz[l]; g.ldz = kTrainCout[l]; g.J = kTrainCout[l]; g.part = w.wpart[l]; g.bpart = w.bpart[l];
+        g.M = M; g.S = S; g.Nb = N; g.rows_per_split = w.wrows[l];
+        const dim3 grid((g.I + TBM - 1) / TBM, 1, w.wsplits[l]);
+        static const bool once = (train_allow_lds(wgrad_gemm_kernel<128>), true);
+        (void)once;
+        if (l == 2) hipLaunchKernelGGL((wgrad_gemm_kernel<128>), grid, dim3(256), train_lds_pad(), s, g);
+        else if (l == 1) hipLaunchKernelGGL((wgrad_gemm_kernel<64>), grid, dim3(256), 0, s, g);
+        else hipLaunchKernelGGL((wgrad_gemm_kernel<32>), grid, dim3(256), 0, s, g);
+        if (l > 0) {
+            ConvGemmArgs a{};
+            a.M = M; a.S = S; a.Nb = N; a.taps = 9;
+            a.src = w.dz[l]; a.Cs = kTrainCout[l]; a.K = 9 * kTrainCout[l]; a.w = w.im.wd[l]; a.act = w.a[l - 1];
+            a.out = w.dz[l - 1]; a.N = kTrainCin[l]; a.ldo = kTrainCin[l];
+            if (l == 2) launch_conv_gemm<AZG_TRAIN_BD3, 1>(s, a);
+            else launch_conv_gemm<32, 1>(s, a);
+        }
+    }
+    GradSegs gs{};
+    auto seg = [&](const float *part, int size, int splits, int kind, int a, int b) {
+        GradSeg &q = gs.s[gs.n++];
+        q.part = part; q.start = gs.total; q.size = size; q.splits = splits; q.kind = kind; q.a = a; q.b = b;
+        gs.total += size;
+    };
+    for (int l = 0; l < 3; l++) {
+        seg(w.wpart[l], 9 * kTrainCin[l] * kTrainCout[l], w.wsplits[l], GS_CONV_W, 2 * l, kTrainCin[l]);
+        seg(w.bpart[l], kTrainCout[l], w.wsplits[l], GS_PLAIN, 2 * l + 1, 0);
+    }
+    seg(w.hpart, 128 * 8, w.hsplits, GS_HEAD_W, 0, 0);
+    seg(w.hbpart, 8, w.hsplits, GS_HEAD_B, 0, 0);
+    seg(w.ppart, 4 * S * S, w.fsplits, GS_FC_W, 8, S);
+    seg(w.pbpart, S, w.fsplits, GS_PLAIN, 9, 0);
+    seg(w.vpart, 2 * S * 64, w.fsplits, GS_FC_W, 12, 64);
+    seg(w.vbpart, 64, w.fsplits, GS_PLAIN, 13, 0);
+    seg(w.g2part, 128, w.gsplits, GS_G2, 0, 0);
+    hipLaunchKernelGGL(grad_assemble_kernel, dim3((gs.total + 255) / 256), dim3(256), 0, s, gs, S, grads);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipMemcpyAsync(w.h_loss, w.lossout, 8, hipMemcpyDeviceToHost, s));
+    return AZG_OK;
+}
+
+static int train_adam_enqueue(azg_handle *h, const TrainParams &P, const float *grads, float *adam_m, float *adam_v, int64_t step,
+                              double lr, double beta1, double beta2, double eps, double weight_decay)
+{
+    const ParamLayout L = param_layout(h->st.S);
+    AdamArgs a{};
+    a.grad = grads; a.m = adam_m; a.v = adam_v; a.total = L.off[16];
+    const double bc1 = 1.0 - std::pow(beta1, (double)step), bc2 = 1.0 - std::pow(beta2, (double)step);
+    a.one_minus_b1 = (float)(1.0 - beta1); a.b2 = (float)beta2; a.one_minus_b2 = (float)(1.0 - beta2);
+    a.neg_step_size = (float)(-(lr / bc1)); a.bc2_sqrt = (float)std::sqrt(bc2); a.eps = (float)eps; a.wd = (float)weight_decay;
+    hipLaunchKernelGGL(adam_kernel, dim3((a.total + 255) / 256), dim3(256), 0, h->tw.stream, P, L, a);
+    HIPCHK(h, hipGetLastError());
+    return AZG_OK;
+}
+
+extern "C" int azg_train_backward(azg_handle *h, int n, const float *states, const float *mcts_probs, const float *winners,
+                                  const float *const params[16], float *grads, float *loss, float *entropy)
+{
+    if (!h || n < 1 || !states || !mcts_probs || !winners || !grads) return fail(h, AZG_EINVAL, "bad argument");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    int rc = train_check_ptrs(h, params);
+    if (rc) return rc;
+    if (!is_device_ptr(states) || !is_device_ptr(grads))
+        return fail(h, AZG_EINVAL, "azg_train_backward takes device pointers (loss and entropy are host pointers)");
+    if ((rc = train_prepare(h, n))) return rc;
+    TrainParams P;
+    for (int i = 0; i < 16; i++) P.p[i] = const_cast<float *>(params[i]);
+    if ((rc = train_backward_enqueue(h, n, states, mcts_probs, winners, P, grads))) return rc;
+    HIPCHK(h, hipStreamSynchronize(h->tw.stream));
+    if (loss) *loss = h->tw.h_loss[0];
+    if (entropy) *entropy = h->tw.h_loss[1];
+    return AZG_OK;
+}
+
+extern "C" int azg_train_adam(azg_handle *h, float *const params[16], const float *grads, float *adam_m, float *adam_v,
+                              int64_t step, double lr, double beta1, double beta2, double eps, double weight_decay)
+{
+    if (!h || !grads || !adam_m || !adam_v || step < 1) return fail(h, AZG_EINVAL, "bad argument");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    int rc = train_check_ptrs(h, params);
+    if (rc) return rc;
+    if (!is_device_ptr(grads) || !is_device_ptr(adam_m) || !is_device_ptr(adam_v)) return fail(h, AZG_EINVAL, "azg_train_adam takes device pointers");
+    if ((rc = train_prepare(h, std::max(1, h->tw.cap_n)))) return rc;
+    TrainParams P;
+    for (int i = 0; i < 16; i++) P.p[i] = params[i];
+    if ((rc = train_adam_enqueue(h, P, grads, adam_m, adam_v, step, lr, beta1, beta2, eps, weight_decay))) return rc;
+    HIPCHK(h, hipStreamSynchronize(h->tw.stream));
+    return AZG_OK;
+}
+
+extern "C" int azg_train_step(azg_handle *h, int n, const float *states, const float *mcts_probs, const float *winners,
+                              float *const params[16], float *grads, float *adam_m, float *adam_v, int64_t step, double lr,
+                              double beta1, double beta2, double eps, double weight_decay, float *loss, float *entropy)
+{
+    if (!h || n < 1 || !states || !mcts_probs || !winners || !grads || !adam_m || !adam_v || step < 1) return fail(h, AZG_EINVAL, "bad argument");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    int rc = train_check_ptrs(h, params);
+    if (rc) return rc;
+    if (!is_device_ptr(states) || !is_device_ptr(grads) || !is_device_ptr(adam_m))
+        return fail(h, AZG_EINVAL, "azg_train_step takes device pointers (loss and entropy are host pointers)");
+    if ((rc = train_prepare(h, n))) return rc;
+    TrainParams P;
+    for (int i = 0; i < 16; i++) P.p[i] = params[i];
+    if ((rc = train_backward_enqueue(h, n, states, mcts_probs, winners, P, grads))) return rc;
+    if ((rc = train_adam_enqueue(h, P, grads, adam_m, adam_v, step, lr, beta1, beta2, eps, weight_decay))) return rc;
+    HIPCHK(h, hipStreamSynchronize(h->tw.stream));
+    if (loss) *loss = h->tw.h_loss[0];
+    if (entropy) *entropy = h->tw.h_loss[1];
+    return AZG_OK;
+}
+
+extern "C" int azg_train_param_count(azg_handle *h)
+{
+    return h ? param_layout(h->st.S).off[16] : AZG_EINVAL;
 }
 
 // Diagnostic builds (-DAZG_STAMPS) only: 32 summed phase counters, then per workgroup of the

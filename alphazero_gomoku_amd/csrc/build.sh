@@ -6,9 +6,9 @@
 #   adjacent multiply-adds into v_pk_fma_f32; in the kernel whose tree waves share their SIMDs with
 #   matrix-dense waves such an operation, fed its x from the high dword of a register pair
 #   (op_sel:[0,1,0]), came out one term short in lanes 48-55 (50-70 of 256 identical searches wrong;
-#   the note at AZG_EXP_PKFC in azg_dual.hpp has the measurements).  The build FAILS when the device
-#   code holds any two-wide float32 instruction (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32), whatever
-#   flag or compiler version produced it.
+#   the note at AZG_EXP_PKFC in azg_dual.hpp has the measurements).  The build FAILS when a search or
+#   evaluation kernel holds any two-wide float32 instruction (v_pk_fma_f32 / v_pk_mul_f32 /
+#   v_pk_add_f32), whatever flag or compiler version produced it.
 #  -no-hip-rt leaves the HIP runtime symbols undefined: the process must hold exactly ONE HIP
 #   runtime, and PyTorch ships its own libamdhip64.so.  The loader (alphazero_gomoku_amd/_lib.py)
 #   loads the runtime PyTorch will use (or /opt/rocm's when PyTorch is absent) with RTLD_GLOBAL
@@ -25,8 +25,12 @@ trap 'rm -rf "$tmp"' EXIT
     "$here/azgomoku.hip" -o "$out" -lpthread "$@" ) 2> "$log" || { cat "$log" >&2; rm -f "$log"; exit 1; }
 asm="$(ls "$tmp"/*gfx950.s 2>/dev/null | head -1)"
 if [ -z "$asm" ]; then echo "build.sh: no device assembly to check" >&2; rm -f "$out" "$log"; exit 1; fi
-if grep -nE "v_pk_(fma|mul|add)_f32" "$asm" | head -5 | grep . >&2; then
-    echo "build.sh: two-wide float32 instructions in the device code (see above): refusing to ship this library" >&2
+# (only the kernels that run beside matrix-dense waves: search, evaluation, caller-evaluated playouts;
+#  the training kernels may use two-wide arithmetic)
+bad="$(awk '/^_ZN3azg[^ ]*:/ { fn = $1 } /v_pk_(fma|mul|add)_f32/ && fn ~ /search_|eval_kernel|playout_/ { print fn " " $0 }' "$asm" | head -5)"
+if [ -n "$bad" ]; then
+    echo "$bad" >&2
+    echo "build.sh: two-wide float32 instructions in a search / evaluation kernel (see above): refusing to ship this library" >&2
     rm -f "$out" "$log"; exit 1
 fi
 # compiler warnings, without the resource-usage remarks and their source excerpts

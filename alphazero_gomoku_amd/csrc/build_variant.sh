@@ -14,5 +14,5 @@ slp="-fno-slp-vectorize"; [ "${AZG_SLP:-0}" = 1 ] && slp=""
 keep=""; [ "${AZG_KEEP:-0}" = 1 ] && keep="-save-temps=obj"
 hipcc --offload-arch=gfx950 -O3 -ffp-contract=off $slp $keep -fPIC -shared -std=c++17 -no-hip-rt -DAZG_ONLY${AZG_ONLY:-8} \
     -Rpass-analysis=kernel-resource-usage "$here/azgomoku.hip" -o "$out" -lpthread "$@" 2> "$log" || { tail -30 "$log" >&2; exit 1; }
-grep -A12 -E "Function Name: _ZN3azg(21search_kernel_f16_8x8|18search_dual_kernel|13search_kernelILi8ELi[0-9]ELi0ELb1)" "$log" | grep -E "VGPRs:|Spill|LDS Size|Occupancy" | sed "s/^.*remark: [^ ]* //" | tr '\n' ' '
+[ "${AZG_QUIET:-0}" = 1 ] || grep -A12 -E "Function Name: _ZN3azg(21search_kernel_f16_8x8|18search_dual_kernel|13search_kernelILi8ELi[0-9]ELi0ELb1)" "$log" | grep -E "VGPRs:|Spill|LDS Size|Occupancy" | sed "s/^.*remark: [^ ]* //" | tr '\n' ' '
 echo " -> $out"

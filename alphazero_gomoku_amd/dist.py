@@ -118,6 +118,18 @@ def max_over_ranks(x, device, group=None):
     return float(t[0])
 
 
+def allreduce_flat(flat, group=None):
+    """Average the flat gradient vector `flat` over the ranks in place (one all_reduce)."""
+    world = dist.get_world_size(group)
+    if world == 1:
+        return
+    own = flat.device
+    buf = flat.to(_comm_device(own, group))                  # gloo: through the host
+    dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+    flat.copy_(buf.to(own))
+    flat /= world
+
+
 def allreduce_gradients(module, group=None):
     """Data-parallel training step (one rank per GPU, each on its share of the mini-batch):
     average the gradients of `module` over the ranks.  The whole network is 119 k parameters at

@@ -1,8 +1,12 @@
 """PolicyValueNet with the reference's surface (policy_value_net_pytorch.py:60-157).
 
-PyTorch only holds the parameters (and, for train_step, the optimiser and autograd);
-every forward used by search or by policy_value / policy_value_fn runs in the HIP
-engine's CNN kernel from a packed copy of those parameters."""
+PyTorch only holds the parameters: every forward used by search or by policy_value /
+policy_value_fn runs in the HIP engine's CNN kernel from a packed copy of them, and train_step is
+the library's own float32 forward / backward / Adam (azg_train_*, csrc/azg_train.hpp) on the
+parameter tensors in place.  The PyTorch autograd version of the same step (train_step_tensors)
+is kept as the float32 reference the tests compare against and for CPU tensors."""
+import ctypes as C
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -84,7 +88,7 @@ def train_step_tensors(module, optimizer, s, p, z, lr, reduce_fn=None):
 
 
 class PolicyValueNet(object):
-    def __init__(self, board_width, board_height, model_file=None, use_gpu=True, device=0):
+    def __init__(self, board_width, board_height, model_file=None, use_gpu=True, device=0, native_train=True):
         if board_width != board_height:
             raise ValueError("only square boards are supported by the HIP engine")
         if not torch.cuda.is_available():
@@ -99,6 +103,12 @@ class PolicyValueNet(object):
         if model_file:
             self.load_model(model_file)
         self.data_parallel = False   # True: train_step averages gradients over torch.distributed ranks
+        # native_train: train_step runs in the HIP library; False: PyTorch autograd + torch.optim.Adam
+        # (the two keep separate optimiser states: use one or the other on a net)
+        self.native_train = bool(native_train)
+        self._adam = None            # (grad, m, v) flat float32 vectors in state_dict order, step count
+        self._ptr_cache = None
+        self._adam_step = 0
         self._eval_engine = None
         self._eval_version = -1
 
@@ -178,12 +188,19 @@ class PolicyValueNet(object):
             engine.set_weights(self.param_tensors(), _lib.LAYOUT_TORCH)
         return self.version
 
-    def _engine(self):
+    def _engine_handle(self):
+        """The net's own library handle (training calls work on the parameter tensors themselves and
+        need no packed copy)."""
         if self._eval_engine is None:
             self._eval_engine = SelfPlayEngine(self.board_width, min(5, self.board_width), 1, 1,
                                                device=self.device.index or 0, arena_nodes=8)
-        self._eval_version = self.sync_engine(self._eval_engine, self._eval_version)
         return self._eval_engine
+
+    def _engine(self):
+        """The same handle with its packed copy of the parameters brought up to date (policy_value, policy_value_fn)."""
+        eng = self._engine_handle()
+        self._eval_version = self.sync_engine(eng, self._eval_version)
+        return eng
 
     # ---- reference surface -----------------------------------------------------
     def policy_value(self, state_batch):
@@ -195,14 +212,32 @@ class PolicyValueNet(object):
         probs, vals = self._engine().eval_batch(np.asarray(state_batch, dtype=np.float32))
         return probs, vals.reshape(-1, 1)
 
+    def _param_ptrs(self):
+        """The 16 parameter tensors' device pointers (PyTorch layout) for the azg_train_* calls; the
+        tensors are the module's own storage, so an update in place is the module's update."""
+        if self._ptr_cache is None:                          # load_* copy into the same storage: the pointers stay
+            ts = [p.data for p in (dict(self.policy_value_net.named_parameters())[k] for k in PARAM_ORDER)]
+            self._ptr_cache = ((C.c_void_p * 16)(*[t.data_ptr() for t in ts]), ts)
+        return self._ptr_cache
+
     def policy_value_in_training(self, state_batch):
-        """(probs [B,S], value [B,1]) of a CUDA batch from the autograd module itself, for the KL
-        monitor inside policy_update: between two train steps of one update the engine's packed
-        copy of the weights is not refreshed (repacking them costs more than the train step); the
-        two forward passes agree to 1e-7."""
-        with torch.no_grad():
-            logp, v = self.policy_value_net(state_batch.to(device=self.device, dtype=torch.float32))
-        return torch.exp(logp), v.reshape(-1, 1)
+        """(probs [B,S], value [B,1]) of a CUDA batch for the KL monitor inside policy_update, from the
+        parameters as they are NOW (between two train steps of one update the search engine's packed
+        copy is not refreshed): the library's float32 forward pass, azg_train_forward."""
+        st = state_batch.to(device=self.device, dtype=torch.float32).contiguous()
+        if not self.native_train:
+            with torch.no_grad():
+                logp, v = self.policy_value_net(st)
+            return torch.exp(logp), v.reshape(-1, 1)
+        n, s = int(st.shape[0]), self.board_width * self.board_height
+        probs = torch.empty((n, s), dtype=torch.float32, device=self.device)
+        vals = torch.empty(n, dtype=torch.float32, device=self.device)
+        eng = self._engine_handle()
+        arr, keep = self._param_ptrs()
+        torch.cuda.current_stream(self.device).synchronize()
+        eng._chk(eng.L.azg_train_forward(eng.h, n, C.c_void_p(st.data_ptr()), arr, C.c_void_p(probs.data_ptr()),
+                                         C.c_void_p(vals.data_ptr())))
+        return probs, vals.reshape(-1, 1)
 
     def policy_value_fn(self, board):
         """policy_value_net_pytorch.py:96-115: (zip(legal moves, probs), value)."""
@@ -211,24 +246,71 @@ class PolicyValueNet(object):
         probs, vals = self._engine().eval_batch(st.astype(np.float32))
         return zip(legal, probs[0][legal]), float(vals[0])
 
+    def native_gradients(self, state_batch, mcts_probs, winner_batch):
+        """(flat gradient in state_dict order as a new CUDA tensor, loss, entropy) of the library's
+        backward pass on a batch, without touching the parameters (tests; gradient inspection)."""
+        dev = self.device
+        s = torch.as_tensor(np.asarray(state_batch), dtype=torch.float32, device=dev).contiguous() if not torch.is_tensor(state_batch) \
+            else state_batch.to(device=dev, dtype=torch.float32).contiguous()
+        p = torch.as_tensor(np.asarray(mcts_probs), dtype=torch.float32, device=dev).contiguous() if not torch.is_tensor(mcts_probs) \
+            else mcts_probs.to(device=dev, dtype=torch.float32).contiguous()
+        z = torch.as_tensor(np.asarray(winner_batch), dtype=torch.float32, device=dev).contiguous().reshape(-1) if not torch.is_tensor(winner_batch) \
+            else winner_batch.to(device=dev, dtype=torch.float32).contiguous().reshape(-1)
+        eng = self._engine_handle()
+        grad = torch.zeros(int(eng.L.azg_train_param_count(eng.h)), dtype=torch.float32, device=dev)
+        arr, keep = self._param_ptrs()
+        loss, entropy = C.c_float(0.0), C.c_float(0.0)
+        torch.cuda.current_stream(dev).synchronize()
+        eng._chk(eng.L.azg_train_backward(eng.h, int(s.shape[0]), C.c_void_p(s.data_ptr()), C.c_void_p(p.data_ptr()),
+                                          C.c_void_p(z.data_ptr()), arr, C.c_void_p(grad.data_ptr()), C.byref(loss), C.byref(entropy)))
+        return grad, float(loss.value), float(entropy.value)
+
     def train_step(self, state_batch, mcts_probs, winner_batch, lr):
         """policy_value_net_pytorch.py:117-148 (loss = MSE(v,z) - mean(pi . log p), Adam with
         weight decay 1e-4); returns Python floats (the reference's loss.data[0] indexing
-        no longer works on current PyTorch)."""
+        no longer works on current PyTorch).  With data_parallel every rank passes its share of the
+        mini-batch and the gradients are averaged over the ranks before the update."""
         dev = self.device
 
         def tensor(a):
             if torch.is_tensor(a):
                 return a.to(device=dev, dtype=torch.float32)
             return torch.as_tensor(np.asarray(a), dtype=torch.float32, device=dev)
-        reduce_fn = None
-        if self.data_parallel and torch.distributed.is_available() and torch.distributed.is_initialized():
-            from .dist import allreduce_gradients
-            reduce_fn = allreduce_gradients                  # every rank holds an equal share of the batch
-        loss, entropy = train_step_tensors(self.policy_value_net, self.optimizer, tensor(state_batch), tensor(mcts_probs),
-                                           tensor(winner_batch), lr, reduce_fn)
+        dp = self.data_parallel and torch.distributed.is_available() and torch.distributed.is_initialized()
+        if not self.native_train:
+            reduce_fn = None
+            if dp:
+                from .dist import allreduce_gradients
+                reduce_fn = allreduce_gradients                  # every rank holds an equal share of the batch
+            loss, entropy = train_step_tensors(self.policy_value_net, self.optimizer, tensor(state_batch), tensor(mcts_probs),
+                                               tensor(winner_batch), lr, reduce_fn)
+            self.version += 1
+            return float(loss.item()), float(entropy.item())
+        s, p, z = tensor(state_batch).contiguous(), tensor(mcts_probs).contiguous(), tensor(winner_batch).contiguous().reshape(-1)
+        n = int(s.shape[0])
+        eng = self._engine_handle()
+        if self._adam is None:
+            total = int(eng.L.azg_train_param_count(eng.h))
+            self._adam = tuple(torch.zeros(total, dtype=torch.float32, device=dev) for _ in range(3))
+        grad, m, v = self._adam
+        arr, keep = self._param_ptrs()
+        loss, entropy = C.c_float(0.0), C.c_float(0.0)
+        torch.cuda.current_stream(dev).synchronize()           # the batch exists before the library's stream reads it
+        self._adam_step += 1
+        if dp:
+            from .dist import allreduce_flat
+            eng._chk(eng.L.azg_train_backward(eng.h, n, C.c_void_p(s.data_ptr()), C.c_void_p(p.data_ptr()), C.c_void_p(z.data_ptr()),
+                                              arr, C.c_void_p(grad.data_ptr()), C.byref(loss), C.byref(entropy)))
+            allreduce_flat(grad)                                 # one collective: the whole gradient is one vector
+            torch.cuda.current_stream(dev).synchronize()
+            eng._chk(eng.L.azg_train_adam(eng.h, arr, C.c_void_p(grad.data_ptr()), C.c_void_p(m.data_ptr()), C.c_void_p(v.data_ptr()),
+                                          self._adam_step, float(lr), 0.9, 0.999, 1e-8, self.l2_const))
+        else:
+            eng._chk(eng.L.azg_train_step(eng.h, n, C.c_void_p(s.data_ptr()), C.c_void_p(p.data_ptr()), C.c_void_p(z.data_ptr()), arr,
+                                          C.c_void_p(grad.data_ptr()), C.c_void_p(m.data_ptr()), C.c_void_p(v.data_ptr()),
+                                          self._adam_step, float(lr), 0.9, 0.999, 1e-8, self.l2_const, C.byref(loss), C.byref(entropy)))
         self.version += 1
-        return float(loss.item()), float(entropy.item())
+        return float(loss.value), float(entropy.value)
 
     def get_policy_param(self):
         return self.policy_value_net.state_dict()

@@ -239,6 +239,36 @@ int azg_board_step_batch_static(azg_handle *h, int n, uint64_t *stones, int32_t 
 int azg_equi_data(azg_handle *h, int n, const float *states, const double *pi, const float *z,
                   float *states_out, double *pi_out, float *z_out);
 
+/* PolicyValueNet.train_step (policy_value_net_pytorch.py:117-148) on a mini-batch of n tuples, in
+ * float32, as three calls so that a data-parallel caller can average the gradients in between:
+ *   azg_train_backward  forward pass (Net.forward, :43-57), loss = mse_loss(value, winners) -
+ *                       mean(sum(mcts_probs * log p, 1)), its gradient with respect to the 16 parameter
+ *                       tensors as ONE flat vector in state_dict order (azg_train_param_count floats),
+ *                       and the two numbers train_step returns: loss and entropy = -mean(sum(p log p, 1))
+ *                       (host pointers, may be NULL);
+ *   azg_train_adam      torch.optim.Adam's update (:65-67: weight decay added to the gradient) of the
+ *                       parameters in place from that vector; adam_m / adam_v are the caller's moment
+ *                       vectors (zero before step 1), step counts from 1;
+ *   azg_train_forward   the forward pass alone: probs = exp(log_softmax) [n,S] and values [n], what
+ *                       PolicyValueNet.policy_value (:80-94) gives for the KL test of train.py:187-201.
+ * states f32 [n,4,N,N], mcts_probs f32 [n,S], winners f32 [n], params: the 16 tensors of
+ * policy_value_net_pytorch.py:31-41 in PyTorch's layout; ALL of these, grads, adam_m, adam_v, probs and
+ * values are DEVICE pointers.  The calls run on a stream of their own (not behind a search in flight)
+ * and are synchronous on return. */
+int azg_train_param_count(azg_handle *h);
+int azg_train_forward(azg_handle *h, int n, const float *states, const float *const params[16],
+                      float *probs, float *values);
+int azg_train_backward(azg_handle *h, int n, const float *states, const float *mcts_probs,
+                       const float *winners, const float *const params[16], float *grads,
+                       float *loss, float *entropy);
+int azg_train_adam(azg_handle *h, float *const params[16], const float *grads, float *adam_m,
+                   float *adam_v, int64_t step, double lr, double beta1, double beta2, double eps,
+                   double weight_decay);
+int azg_train_step(azg_handle *h, int n, const float *states, const float *mcts_probs,
+                   const float *winners, float *const params[16], float *grads, float *adam_m,
+                   float *adam_v, int64_t step, double lr, double beta1, double beta2, double eps,
+                   double weight_decay, float *loss, float *entropy);
+
 /* Timing of the search kernel, measured with HIP events on the handle's stream:
  * number of launches since the last call, summed milliseconds, and summed leaf
  * evaluations (playouts that reached the CNN).  Resets the counters. */

@@ -24,7 +24,57 @@ def _policy_from(ev, oracle, n, k):
     return policy
 
 
-def test_train_step_matches_reference(az):
+@pytest.mark.parametrize("n,batch", [(8, 37), (8, 512), (6, 64), (15, 20), (11, 3)])
+def test_native_gradients_match_autograd(az, n, batch):
+    """The library's float32 backward pass (azg_train_backward: implicit-GEMM convolutions on the
+    float32 matrix cores, heads, fully connected layers, both losses) against the reference's loss
+    (policy_value_net_pytorch.py:128-141) differentiated by PyTorch autograd in FLOAT64 on the CPU, with
+    PyTorch's own float32 GPU gradients as the yardstick: every one of the 16 gradient tensors is at
+    most three times as far from the float64 gradient as PyTorch's float32 one is (plus 2e-6 of the
+    tensor's largest entry; large batches put a few head pre-activations within float32 noise of
+    zero, which moves both float32 gradients by the same 1e-4); loss and entropy to 1e-5; the forward
+    pass alone (azg_train_forward) to 1e-6.  Batches that do not fill the 128-row tiles included."""
+    import copy
+    import torch
+    import torch.nn.functional as F
+    from alphazero_gomoku_amd.net import PARAM_ORDER
+    S = n * n
+    rs = np.random.RandomState(n * 1000 + batch)
+    net = az.PolicyValueNet(n, n)
+    net.load_numpy_params(helpers.make_params(n, seed=300 + n, scale=1.5))
+    s = (rs.rand(batch, 4, n, n) < 0.3).astype(np.float32)
+    pi = rs.dirichlet(np.full(S, 0.3), size=batch).astype(np.float32)
+    z = rs.choice([-1.0, 0.0, 1.0], size=batch).astype(np.float32)
+    grad, loss, ent = net.native_gradients(s, pi, z)
+
+    def autograd(mod, dev, dt):
+        mod.zero_grad()
+        logp, v = mod(torch.as_tensor(s, device=dev, dtype=dt))
+        lo = F.mse_loss(v.view(-1), torch.as_tensor(z, device=dev, dtype=dt)) - torch.mean(torch.sum(torch.as_tensor(pi, device=dev, dtype=dt) * logp, 1))
+        lo.backward()
+        en = -torch.mean(torch.sum(torch.exp(logp) * logp, 1))
+        return {k: p.grad.detach().double().cpu().reshape(-1) for k, p in mod.named_parameters()}, float(lo.detach()), float(en.detach()), logp.detach(), v.detach()
+    g32, _, _, logp32, v32 = autograd(net.policy_value_net, net.device, torch.float32)
+    g64, loss64, ent64, _, _ = autograd(copy.deepcopy(net.policy_value_net).double().cpu(), "cpu", torch.float64)
+    assert abs(loss - loss64) < 1e-5 and abs(ent - ent64) < 1e-5
+    off = 0
+    for key in PARAM_ORDER:
+        k = g64[key].numel()
+        mine = grad[off:off + k].double().cpu()
+        off += k
+        scale = float(g64[key].abs().max())
+        err, err32 = float((mine - g64[key]).abs().max()), float((g32[key] - g64[key]).abs().max())
+        assert err <= 3.0 * err32 + 2e-6 * scale + 1e-10, (key, err, err32, scale)
+    assert off == grad.numel()
+    probs, vals = net.policy_value_in_training(torch.as_tensor(s, device=net.device))
+    assert float((probs - torch.exp(logp32)).abs().max()) < 1e-6 and float((vals - v32).abs().max()) < 1e-6
+    # and it is the same bits every time
+    grad2, loss2, ent2 = net.native_gradients(s, pi, z)
+    assert torch.equal(grad, grad2) and loss == loss2 and ent == ent2
+
+
+@pytest.mark.parametrize("native", [True, False], ids=["hip", "autograd"])
+def test_train_step_matches_reference(az, native):
     """PolicyValueNet.train_step on the GPU against the reference's train_step (fixture g9,
     policy_value_net_pytorch.py:117-148): loss and entropy of three steps to 1e-5, the parameters
     after one and three Adam steps, and the HIP CNN's outputs with the updated weights against the
@@ -33,7 +83,7 @@ def test_train_step_matches_reference(az):
     float32 noise of zero can land 2*lr away on another device; those are counted, not hidden."""
     d = helpers.load_golden("g9_train.npz")
     n, k, seed = [int(x) for x in d["spec"]]
-    net = az.PolicyValueNet(n, n)
+    net = az.PolicyValueNet(n, n, native_train=native)
     net.load_numpy_params(helpers.make_params(n, seed=seed))
     v0 = net.version
     s, p, z = d["states"].astype(np.float32), d["pi"], d["z"]
