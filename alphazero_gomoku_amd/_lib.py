@@ -113,7 +113,7 @@ def load():
     L.azg_gate_stats.argtypes = [vp, i64p, i64p]
     L.azg_gate_poke.argtypes = [vp, C.c_int]
     L.azg_train_param_count.argtypes = [vp]
-    L.azg_train_forward.argtypes = [vp, C.c_int, vp, C.POINTER(vp), vp, vp]
+    L.azg_train_forward.argtypes = [vp, C.c_int, vp, C.POINTER(vp), vp, vp, vp, C.POINTER(C.c_double)]
     L.azg_train_backward.argtypes = [vp, C.c_int, vp, vp, vp, C.POINTER(vp), vp, f32p, f32p]
     L.azg_train_adam.argtypes = [vp, C.POINTER(vp), vp, vp, vp, C.c_int64, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double]
     L.azg_train_step.argtypes = [vp, C.c_int, vp, vp, vp, C.POINTER(vp), vp, vp, vp, C.c_int64, C.c_double, C.c_double,

@@ -14,8 +14,7 @@
 //   backward weights dW[(t,ci)][co] = sum_m X[m + off_t][ci] dY[m][co]           wgrad_gemm_kernel
 // Activations are channels-last ([row m = sample * S + cell][channel]), so a row of 4 consecutive k
 // (one tap, four channels) is one 16-byte load and a 3x3 tap is a row offset; a tap that leaves the
-// board reads zero.  Nothing is unfolded in memory.  Tiles live in LDS k-major ([k][row]), so the
-// lanes of an MFMA operand read consecutive words.  The small layers (1x1 heads as a GEMM with one
+// board reads zero.  Nothing is unfolded in memory.  The small layers (1x1 heads as a GEMM with one
 // tap, fully connected layers, losses) and Adam are plain kernels; every sum over the batch has a
 // fixed order, so a step gives the same bits every time.
 #pragma once
@@ -24,6 +23,12 @@
 
 namespace azg {
 
+// Timing experiments on conv_gemm_kernel (results are WRONG with any bit set): 1 no global loads in the
+// loop, 2 no staging stores, 4 no barrier, 8 no operand reads from LDS, 16 no output stores, 32 no
+// matrix instructions.
+#ifndef AZG_TRAIN_EXP
+#define AZG_TRAIN_EXP 0
+#endif
 constexpr int TBM = 128;       // rows of a block tile (4 waves x 32)
 constexpr int TKC = 16;        // k per LDS stage
 
@@ -37,73 +42,108 @@ struct ConvGemmArgs {
     int M, N, Cs, K, taps, S, Nb, ldo;
 };
 
+// On this chip a float32 matrix instruction and the ordinary vector instructions of ANY wave of the same
+// SIMD do not overlap: a wave that issues v_mfma_f32_32x32x2f32 back to back reaches 137 TFLOP/s in a
+// 35 us launch, and every four vector additions per matrix instruction add 23 cycles to its 64, with one,
+// two or four waves per SIMD alike (tests/micro/mfma_f32_rate.hip).  So the loops below are written for the
+// fewest vector instructions per stage, not for interleaving:
+//   * global loads are buffer loads: an element that is off the board, past K or past M gets an offset
+//     beyond the buffer's size and the hardware returns zeros (no select, no branch, 32-bit offsets);
+//   * which of the nine taps of a row's cell are on the board is a 9-bit mask computed once; a stage's
+//     tap is uniform over the workgroup when the channel count is a multiple of the stage's 16 k, so its
+//     row shift and bit are scalar arithmetic;
+//   * tiles lie in LDS row-major with k innermost ([row][16 k + 4 pad]): a 16-byte global load is one
+//     16-byte LDS store, and a lane's eight k of a stage are two 16-byte LDS loads.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr int kBufferOob = 0x7fffffff;                       // an offset no buffer here reaches
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t train_buffer(const float *p, unsigned bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ f32x4 train_buffer_load(__amdgpu_buffer_rsrc_t r, int byte_offset)
+{
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, byte_offset, 0, 0));
+}
+constexpr int TLK = TKC + 4;   // words per tile row: 16-lane groups of the 16-byte operand loads hit every bank once
+
 // MODE 0: out = relu(acc + bias);  1: out = act > 0 ? acc : 0;  2: the two 1x1 head convolutions:
 // relu(acc + bias) of column c < 4 goes to out[b][c*S + p], of column 4, 5 to out2[b][(c-4)*S + p] (row stride ldo)
 // (the order view(-1, 4*S) / view(-1, 2*S) flattens in, policy_value_net_pytorch.py:50,54);
 // 3: out = acc + bias (no activation).
-template <int BN, int MODE>
+// CS4: the source has 4 channels (the input planes): a stage's 16 k are four taps, one per thread of a row's
+// four; otherwise the channel count must be a multiple of 16.  The source holds M * Cs floats, w holds N * K.
+template <int BN, int MODE, bool CS4 = false>
 __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvGemmArgs a)
 {
-    // Row stride = 4 (mod 64 words): the transposing stores of a wave (16 rows x 4 float4, word j of each)
-    // fall on banks 16 k4 + 4 j + row, all different; the operand reads of the two lane halves are rows
-    // q and q + 8, 32 banks apart.
-    __shared__ float As[2][TKC][TBM + 4];
-    __shared__ float Bs[2][TKC][BN + 4];
+    __shared__ __attribute__((aligned(16))) float As[2][TBM][TLK];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BN][TLK];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, h = lane >> 5, l32 = lane & 31;
     const int m0 = blockIdx.x * TBM, n0 = blockIdx.y * BN;
     const int k4 = tid & 3;                                  // this thread's float4 inside a stage's 16 k
-    // A rows of this thread: r = (tid >> 2) + 64 i
-    int abase[2], apr[2], apc[2];
-    bool aval[2];
+    const __amdgpu_buffer_rsrc_t rsrc = train_buffer(a.src, (unsigned)a.M * a.Cs * 4u);
+    const __amdgpu_buffer_rsrc_t rw = train_buffer(a.w, (unsigned)a.N * a.K * 4u);
+    // A rows of this thread: r = (tid >> 2) + 64 i; byte offset of the row's channel 4 k4 and the taps on the board
+    int aoff[2];
+    unsigned amask[2];
 #pragma unroll
     for (int i = 0; i < 2; i++) {
         const int m = m0 + (tid >> 2) + 64 * i;
-        aval[i] = m < a.M;
-        const int mm = aval[i] ? m : 0;
+        const bool ok = m < a.M;
+        const int mm = ok ? m : 0;
         const int b = mm / a.S, p = mm - b * a.S;
-        apr[i] = p / a.Nb;
-        apc[i] = p - apr[i] * a.Nb;
-        abase[i] = mm;
+        const int pr = p / a.Nb, pc = p - pr * a.Nb;
+        unsigned msk = 1u;
+        if (a.taps == 9) {
+            msk = 0u;
+#pragma unroll
+            for (int t = 0; t < 9; t++)
+                msk |= (((unsigned)(pr + t / 3 - 1) < (unsigned)a.Nb) & ((unsigned)(pc + t % 3 - 1) < (unsigned)a.Nb)) ? 1u << t : 0u;
+        }
+        amask[i] = ok ? msk : 0u;
+        aoff[i] = (mm * a.Cs + (CS4 ? 0 : 4 * k4)) * 4;
     }
     constexpr int NBL = (BN * 4 + 255) / 256;                // float4 of B per thread and stage
+    int boff[NBL];
+#pragma unroll
+    for (int i = 0; i < NBL; i++) {
+        const int n = (tid + 256 * i) >> 2;
+        boff[i] = ((n < BN) & (n0 + n < a.N)) ? ((n0 + n) * a.K + 4 * k4) * 4 : kBufferOob;
+    }
     const int nchunks = (a.K + TKC - 1) / TKC;
 
-    // The stages are loaded in order, so this thread's k (tap, channel) advances by TKC per call: no
-    // division in the loop (integer work here is issued beside the matrix instructions, but not for free).
-    int lk = 4 * k4, ltap = lk / a.Cs, lc = lk - ltap * a.Cs;
+    // The stages are loaded in order: the stage's first k as (tap, channel) advances by 16 per call.  A k
+    // past K is a tap past the last one: no bit of the mask, zeros.  (B rows then run into the next row
+    // of w, or past its end into zeros: multiplied by A's zeros either way.)
+    int s_tap = 0, s_c = 0, s_kb = 0;
     auto load = [&](f32x4 (&va)[2], f32x4 (&vb)[NBL]) {
-        const bool kok = lk < a.K;
-        const int tap = kok ? ltap : 0, c = lc;
-        int dr = 0, dc = 0;
-        if (a.taps == 9) { dr = ((tap * 11) >> 5) - 1; dc = tap - 3 * (dr + 1) - 1; }
-        const int shift = dr * a.Nb + dc;
+        if (CS4) {
+            const int tap = s_tap + k4;
+            const int t3 = (tap * 11) >> 5;                  // tap / 3 for tap < 16
+            const int shift = ((t3 - 1) * a.Nb + tap - 3 * t3 - 1) * 16;
 #pragma unroll
-        for (int i = 0; i < 2; i++) {
-            const int rr = apr[i] + dr, cc = apc[i] + dc;
-            const bool ok = kok && aval[i] && (unsigned)rr < (unsigned)a.Nb && (unsigned)cc < (unsigned)a.Nb;
-            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-            va[i] = ok ? *reinterpret_cast<const f32x4 *>(a.src + (size_t)(abase[i] + shift) * a.Cs + c) : z;
+            for (int i = 0; i < 2; i++) va[i] = train_buffer_load(rsrc, ((amask[i] >> tap) & 1u) ? aoff[i] + shift : kBufferOob);
+            s_tap += 4;
+        } else {
+            const int t3 = (s_tap * 11) >> 5;
+            const int cell = a.taps == 9 ? (t3 - 1) * a.Nb + s_tap - 3 * t3 - 1 : 0;
+            const int shift = (cell * a.Cs + s_c) * 4;
+            const unsigned bit = 1u << s_tap;
+#pragma unroll
+            for (int i = 0; i < 2; i++) va[i] = train_buffer_load(rsrc, (amask[i] & bit) ? aoff[i] + shift : kBufferOob);
+            s_c += TKC;
+            if (s_c >= a.Cs) { s_c = 0; s_tap++; }
         }
 #pragma unroll
-        for (int i = 0; i < NBL; i++) {
-            const int q = tid + 256 * i, n = q >> 2;
-            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-            vb[i] = (kok && n < BN && n0 + n < a.N) ? *reinterpret_cast<const f32x4 *>(a.w + (size_t)(n0 + n) * a.K + lk) : z;
-        }
-        lk += TKC; lc += TKC;
-        while (lc >= a.Cs) { lc -= a.Cs; ltap++; }
+        for (int i = 0; i < NBL; i++) vb[i] = train_buffer_load(rw, boff[i] + s_kb);
+        s_kb += TKC * 4;
     };
     auto stage = [&](int st, const f32x4 (&va)[2], const f32x4 (&vb)[NBL]) {
 #pragma unroll
-        for (int i = 0; i < 2; i++)
-#pragma unroll
-            for (int j = 0; j < 4; j++) As[st][4 * k4 + j][(tid >> 2) + 64 * i] = va[i][j];
+        for (int i = 0; i < 2; i++) *reinterpret_cast<f32x4 *>(&As[st][(tid >> 2) + 64 * i][4 * k4]) = va[i];
 #pragma unroll
         for (int i = 0; i < NBL; i++) {
-            const int q = tid + 256 * i, n = q >> 2;
-            if (n < BN)
-#pragma unroll
-                for (int j = 0; j < 4; j++) Bs[st][4 * k4 + j][n] = vb[i][j];
+            const int n = (tid + 256 * i) >> 2;
+            if (BN * 4 % 256 == 0 || n < BN) *reinterpret_cast<f32x4 *>(&Bs[st][n][4 * k4]) = vb[i];
         }
     };
 
@@ -117,43 +157,44 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvGemmArgs a)
     // buffered: a stage's loads have two multiplication phases (about 1.7 us) to arrive.
     f32x4 va[2][2], vb[2][NBL];
     load(va[0], vb[0]);
-    if (nchunks > 1) load(va[1], vb[1]);
+    load(va[1], vb[1]);                                      // (past K: zeros)
     stage(0, va[0], vb[0]);
     __syncthreads();
     // (the stage index is a compile-time constant: register sets must not be indexed at run time)
-    auto body = [&](int kc, auto stc) {
+    auto body = [&](auto stc) {
         constexpr int st = decltype(stc)::value;
-        // every operand of the stage is requested before the first product, so that one LDS round trip is
-        // exposed per stage instead of one per pair of products
-        float av[TKC / 2], bv[TKC / 2][BN / 32];
+        // lane half h multiplies k = 8 h .. 8 h + 7 of the stage, one per matrix instruction; every operand
+        // is requested before the first product: one LDS round trip per stage
+        f32x4 av[2], bv[BN / 32][2];
 #pragma unroll
-        for (int kk = 0; kk < TKC; kk += 2) {              // lane half h takes k = kk/2 + 8 h of the pair
-            av[kk / 2] = As[st][kk / 2 + 8 * h][32 * wave + l32];
+        for (int q = 0; q < 2; q++) {
+            if (AZG_TRAIN_EXP & 8) {
+                av[q] = f32x4{(float)lane, 1.f, 2.f, 3.f};
 #pragma unroll
-            for (int t = 0; t < BN / 32; t++) bv[kk / 2][t] = Bs[st][kk / 2 + 8 * h][32 * t + l32];
+                for (int t = 0; t < BN / 32; t++) bv[t][q] = f32x4{(float)(lane + t), 1.f, 2.f, 3.f};
+                continue;
+            }
+            av[q] = *reinterpret_cast<const f32x4 *>(&As[st][32 * wave + l32][8 * h + 4 * q]);
+#pragma unroll
+            for (int t = 0; t < BN / 32; t++) bv[t][q] = *reinterpret_cast<const f32x4 *>(&Bs[st][32 * t + l32][8 * h + 4 * q]);
         }
-        __builtin_amdgcn_sched_barrier(0);
-        if (kc + 2 < nchunks) load(va[st], vb[st]);          // set `st` was staged in the previous iteration (or above)
+        if (!(AZG_TRAIN_EXP & 1)) load(va[st], vb[st]);      // set `st` was staged in the previous iteration (or above)
 #pragma unroll
-        for (int kk = 0; kk < TKC; kk += 2)
+        for (int j = 0; j < 8; j++)
 #pragma unroll
-            for (int t = 0; t < BN / 32; t++)
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk / 2], bv[kk / 2][t], acc[t], 0, 0, 0);
-        // the next-but-one stage's address arithmetic and loads go between the products (a product holds
-        // the vector issue port for a fraction of its 64 cycles)
-#pragma unroll
-        for (int m = 0; m < (TKC / 2) * (BN / 32); m++) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x006, 8, 0);
-            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        if (kc + 1 < nchunks) stage(st ^ 1, va[st ^ 1], vb[st ^ 1]);
-        __syncthreads();
+            for (int t = 0; t < BN / 32; t++) {
+                if (AZG_TRAIN_EXP & 32) acc[t][j] += av[j >> 2][j & 3] * bv[t][j >> 2][j & 3];
+                else acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j >> 2][j & 3], bv[t][j >> 2][j & 3], acc[t], 0, 0, 0);
+            }
+        if (!(AZG_TRAIN_EXP & 2)) stage(st ^ 1, va[st ^ 1], vb[st ^ 1]);  // (after the last stage: zeros nobody reads)
+        if (!(AZG_TRAIN_EXP & 4)) __syncthreads();
     };
+    // (always in pairs; an odd count ends with a stage of zeros: a conditional second half would be a
+    //  path on which the first half's loads are still in flight at the loop's head, and the wait
+    //  counts the compiler puts there would then drain every iteration's loads)
     for (int kc = 0; kc < nchunks; kc += 2) {
-        body(kc, std::integral_constant<int, 0>{});
-        if (kc + 1 < nchunks) body(kc + 1, std::integral_constant<int, 1>{});
+        body(std::integral_constant<int, 0>{});
+        body(std::integral_constant<int, 1>{});
     }
 
 #pragma unroll
@@ -166,6 +207,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvGemmArgs a)
             const int m = m0 + 32 * wave + acc_row(r, h);
             if (m >= a.M) continue;
             float v = acc[t][r] + bv;
+            if ((AZG_TRAIN_EXP & 16) && v != 12345.678f) continue;
             if (MODE == 0) {
                 a.out[(size_t)m * a.ldo + n] = v > 0.f ? v : 0.f;
             } else if (MODE == 1) {
@@ -195,47 +237,63 @@ struct WgradArgs {
 template <int BN>
 __global__ __launch_bounds__(256, 2) void wgrad_gemm_kernel(WgradArgs a)
 {
+    // (k = the rows m of the split; both tiles arrive k-major from memory: [k][i] and [k][j])
     __shared__ __attribute__((aligned(16))) float As[2][TKC][TBM + 4];
     __shared__ __attribute__((aligned(16))) float Bs[2][TKC][BN + 4];
+    __shared__ unsigned short taps_on_board[256];            // per cell: bit t = tap t of that cell is on the board
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, h = lane >> 5, l32 = lane & 31;
     const int i0 = blockIdx.x * TBM, j0 = blockIdx.y * BN, z = blockIdx.z;
     const int mbeg = z * a.rows_per_split, mend = min(a.M, mbeg + a.rows_per_split);
     const int nchunks = mend > mbeg ? (mend - mbeg + TKC - 1) / TKC : 0;
-    // A: 16 rows (m) x 32 float4 (i): 2 per thread;  B: 16 rows x BN/4 float4
+    if (tid < a.S) {
+        unsigned msk = 1u;
+        if (a.taps == 9) {
+            const int pr = tid / a.Nb, pc = tid - pr * a.Nb;
+            msk = 0u;
+#pragma unroll
+            for (int t = 0; t < 9; t++)
+                msk |= (((unsigned)(pr + t / 3 - 1) < (unsigned)a.Nb) & ((unsigned)(pc + t % 3 - 1) < (unsigned)a.Nb)) ? 1u << t : 0u;
+        }
+        taps_on_board[tid] = (unsigned short)msk;
+    }
+    // A: 16 rows (m) x 32 float4 (i): 2 per thread;  B: 16 rows x BN/4 float4.  Rows from the split's end on
+    // lie past the end of B's buffer (zeros from the hardware), so A needs no row test of its own.
+    const __amdgpu_buffer_rsrc_t rsrc = train_buffer(a.src, (unsigned)a.M * a.Cs * 4u);
+    const __amdgpu_buffer_rsrc_t rdz = train_buffer(a.dz, (unsigned)mend * a.ldz * 4u);
     const int i4 = tid & 31;
     const int ia = i0 + 4 * i4;
     const bool iok = ia < a.I;
     const int tap = iok ? ia / a.Cs : 0, ci = ia - tap * a.Cs;
-    int dr = 0, dc = 0;
-    if (a.taps == 9) { dr = tap / 3 - 1; dc = tap - (tap / 3) * 3 - 1; }
+    const int cell = a.taps == 9 ? (tap / 3 - 1) * a.Nb + tap % 3 - 1 : 0;
+    const unsigned tapbit = iok ? 1u << tap : 0u;
     constexpr int BQ = BN / 4;                               // float4 per B row
     constexpr int NBL = (TKC * BQ + 255) / 256;
-
-    // The stages are loaded in order: this thread's rows advance by TKC per call, their cell p = m mod S
-    // with them; row and column of the cell by one multiplication (p < 256: (p * ceil(2^16 / Nb)) >> 16).
-    const int inv_nb = (65536 + a.Nb - 1) / a.Nb, shift = dr * a.Nb + dc;
-    int lm[2], lp[2];
+    int aoff[2], lp[2], boff[NBL];
 #pragma unroll
-    for (int i = 0; i < 2; i++) { lm[i] = mbeg + (tid >> 5) + 8 * i; lp[i] = lm[i] % a.S; }
-    int lmb = mbeg;
+    for (int i = 0; i < 2; i++) {
+        const int m = mbeg + (tid >> 5) + 8 * i;
+        aoff[i] = ((m + cell) * a.Cs + ci) * 4;
+        lp[i] = m % a.S;
+    }
+#pragma unroll
+    for (int i = 0; i < NBL; i++) {
+        const int q = tid + 256 * i, row = q / BQ, j4 = q - row * BQ, j = j0 + 4 * j4;
+        boff[i] = ((row < TKC) & (j < a.ldz)) ? ((mbeg + row) * a.ldz + j) * 4 : kBufferOob;
+    }
+    __syncthreads();
+    // The stages are loaded in order: this thread's rows advance by 16 per call, their cells p = m mod S with them.
+    const int sstep = TKC % a.S, astep = TKC * a.Cs * 4, bstep = TKC * a.ldz * 4;
+    int s_a = 0, s_b = 0;
     auto load = [&](f32x4 (&va)[2], f32x4 (&vb)[NBL]) {
-        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int i = 0; i < 2; i++) {
-            const int m = lm[i], p = lp[i];
-            const int pr = (p * inv_nb) >> 16, pc = p - pr * a.Nb;
-            const bool ok = iok && m < mend && (unsigned)(pr + dr) < (unsigned)a.Nb && (unsigned)(pc + dc) < (unsigned)a.Nb;
-            va[i] = ok ? *reinterpret_cast<const f32x4 *>(a.src + (size_t)(m + shift) * a.Cs + ci) : zero;
-            lm[i] += TKC; lp[i] += TKC;
-            while (lp[i] >= a.S) lp[i] -= a.S;
+            va[i] = train_buffer_load(rsrc, (taps_on_board[lp[i]] & tapbit) ? aoff[i] + s_a : kBufferOob);
+            lp[i] += sstep;
+            lp[i] -= lp[i] >= a.S ? a.S : 0;
         }
 #pragma unroll
-        for (int i = 0; i < NBL; i++) {
-            const int q = tid + 256 * i, row = q / BQ, j4 = q - row * BQ;
-            const int m = lmb + row, j = j0 + 4 * j4;
-            vb[i] = (row < TKC && m < mend && j < a.ldz) ? *reinterpret_cast<const f32x4 *>(a.dz + (size_t)m * a.ldz + j) : zero;
-        }
-        lmb += TKC;
+        for (int i = 0; i < NBL; i++) vb[i] = train_buffer_load(rdz, boff[i] + s_b);
+        s_a += astep; s_b += bstep;
     };
     auto stage = [&](int st, const f32x4 (&va)[2], const f32x4 (&vb)[NBL]) {
 #pragma unroll
@@ -243,7 +301,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_gemm_kernel(WgradArgs a)
 #pragma unroll
         for (int i = 0; i < NBL; i++) {
             const int q = tid + 256 * i, row = q / BQ, j4 = q - row * BQ;
-            if (row < TKC) *reinterpret_cast<f32x4 *>(&Bs[st][row][4 * j4]) = vb[i];
+            if (TKC * BQ % 256 == 0 || row < TKC) *reinterpret_cast<f32x4 *>(&Bs[st][row][4 * j4]) = vb[i];
         }
     };
 
@@ -253,16 +311,15 @@ __global__ __launch_bounds__(256, 2) void wgrad_gemm_kernel(WgradArgs a)
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[t][r] = 0.f;
     f32x4 va[2][2], vb[2][NBL];
-    if (nchunks > 0) load(va[0], vb[0]);
-    if (nchunks > 1) load(va[1], vb[1]);
-    if (nchunks > 0) stage(0, va[0], vb[0]);
+    load(va[0], vb[0]);
+    load(va[1], vb[1]);
+    stage(0, va[0], vb[0]);
     __syncthreads();
     const bool sums = a.bpart != nullptr && blockIdx.x == 0 && tid < BN;
     float bsum = 0.f;
-    auto body = [&](int kc, auto stc) {
+    auto body = [&](auto stc) {
         constexpr int st = decltype(stc)::value;
-        // every operand of the stage is requested before the first product, so that one LDS round trip is
-        // exposed per stage instead of one per pair of products
+        // every operand of the stage is requested before the first product: one LDS round trip per stage
         float av[TKC / 2], bv[TKC / 2][BN / 32];
 #pragma unroll
         for (int kk = 0; kk < TKC; kk += 2) {              // lane half h takes k = kk/2 + 8 h of the pair
@@ -270,32 +327,23 @@ __global__ __launch_bounds__(256, 2) void wgrad_gemm_kernel(WgradArgs a)
 #pragma unroll
             for (int t = 0; t < BN / 32; t++) bv[kk / 2][t] = Bs[st][kk / 2 + 8 * h][32 * t + l32];
         }
-        __builtin_amdgcn_sched_barrier(0);
-        if (kc + 2 < nchunks) load(va[st], vb[st]);
+        load(va[st], vb[st]);
 #pragma unroll
         for (int kk = 0; kk < TKC; kk += 2)
 #pragma unroll
             for (int t = 0; t < BN / 32; t++)
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk / 2], bv[kk / 2][t], acc[t], 0, 0, 0);
-        // the next-but-one stage's address arithmetic and loads go between the products (a product holds
-        // the vector issue port for a fraction of its 64 cycles)
-#pragma unroll
-        for (int m = 0; m < (TKC / 2) * (BN / 32); m++) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x006, 8, 0);
-            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
         if (sums) {
 #pragma unroll
             for (int k = 0; k < TKC; k++) bsum += Bs[st][k][tid];        // rows past the split's end were staged as zeros
         }
-        if (kc + 1 < nchunks) stage(st ^ 1, va[st ^ 1], vb[st ^ 1]);
+        stage(st ^ 1, va[st ^ 1], vb[st ^ 1]);
         __syncthreads();
     };
+    // (always in pairs, as in conv_gemm_kernel; an odd count ends with a stage of zeros)
     for (int kc = 0; kc < nchunks; kc += 2) {
-        body(kc, std::integral_constant<int, 0>{});
-        if (kc + 1 < nchunks) body(kc + 1, std::integral_constant<int, 1>{});
+        body(std::integral_constant<int, 0>{});
+        body(std::integral_constant<int, 1>{});
     }
     if (sums && j0 + tid < a.J) a.bpart[(size_t)z * a.J + j0 + tid] = bsum;
 #pragma unroll
@@ -624,6 +672,26 @@ __global__ __launch_bounds__(256) void loss_kernel(const float *parts, int n, fl
 // torch.optim.Adam (weight_decay added to the gradient, no amsgrad) on the flat state:
 //   g += wd * p;  m = m + (1 - b1) * (g - m);  v = b2 * v + ((1 - b2) * g) * g;
 //   p += (-(lr / (1 - b1^t)) * m) / (sqrt(v) / sqrt(1 - b2^t) + eps)        (the operation order of its float32 kernels)
+// The KL test of train.py:187-193: mean over the batch of sum_a old * (log(old + 1e-10) - log(new + 1e-10)),
+// in double, summed in a fixed order (one workgroup).
+__global__ __launch_bounds__(1024) void kl_kernel(const float *oldp, const float *newp, int n, int S, double *out)
+{
+    __shared__ double red[1024];
+    const int tid = threadIdx.x, total = n * S;
+    double s = 0.0;
+    for (int i = tid; i < total; i += 1024) {
+        const double o = oldp[i], q = newp[i];
+        s += o * (log(o + 1e-10) - log(q + 1e-10));
+    }
+    red[tid] = s;
+    __syncthreads();
+    for (int w = 512; w > 0; w >>= 1) {
+        if (tid < w) red[tid] += red[tid + w];
+        __syncthreads();
+    }
+    if (tid == 0) out[0] = red[0] / (double)n;
+}
+
 struct AdamArgs {
     const float *grad;
     float *m, *v;

@@ -20,13 +20,13 @@
 #include "azg_kernels.hpp"
 #include "azg_pure.hpp"
 #ifndef AZG_TRAIN_BN3
-#define AZG_TRAIN_BN3 128     // columns per workgroup of conv3's forward GEMM (64: twice the workgroups)
+#define AZG_TRAIN_BN3 64      // columns per workgroup of conv3's forward GEMM (64: two workgroups per CU; 128 measured 3 % slower)
 #endif
 #ifndef AZG_TRAIN_BD3
-#define AZG_TRAIN_BD3 64      // columns per workgroup of conv3's backward-data GEMM (64 columns in all)
+#define AZG_TRAIN_BD3 32      // columns per workgroup of conv3's backward-data GEMM (64 columns in all; 64 measured 3 % slower)
 #endif
 #ifndef AZG_TRAIN_WCAP
-#define AZG_TRAIN_WCAP 64     // most splits of the batch in the weight-gradient GEMMs of conv2 / conv3
+#define AZG_TRAIN_WCAP 128    // most splits of the batch in the weight-gradient GEMMs of conv2 / conv3 (32: 25 % slower step)
 #endif
 #include "azg_train.hpp"
 #include "np_legacy_rng.hpp"
@@ -1637,7 +1637,7 @@ static int train_prepare(azg_handle *h, int n)
     auto &w = h->tw;
     const int S = h->st.S;
     if (!w.stream) HIPCHK(h, hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking));
-    if (!w.h_loss) HIPCHK(h, hipHostMalloc((void **)&w.h_loss, 16));
+    if (!w.h_loss) HIPCHK(h, hipHostMalloc((void **)&w.h_loss, 32));   // loss, entropy; a double at +8: KL
     const int M = n * S;
     for (int l = 0; l < 3; l++) {
         const int tiles = ((9 * kTrainCin[l] + TBM - 1) / TBM);
@@ -1658,7 +1658,7 @@ static int train_prepare(azg_handle *h, int n)
     const size_t o_d0 = take(Mz * 32), o_d1 = take(Mz * 64), o_d2 = take(Mz * 128);
     const size_t o_hp = take((size_t)n * 4 * S), o_hv = take((size_t)n * ldhv), o_dh8 = take(Mz * 8);
     const size_t o_dl = take((size_t)n * Sp), o_dh1 = take((size_t)n * 64), o_g2 = take((size_t)n * 128);
-    const size_t o_lp = take((size_t)n * 3), o_lo = take(4);
+    const size_t o_lp = take((size_t)n * 3), o_lo = take(8);   // lossout: loss, entropy, -, -, a double (KL)
     size_t o_wf[3], o_wd[3], o_wp[3], o_bp[3];
     for (int l = 0; l < 3; l++) {
         o_wf[l] = take((size_t)kTrainCout[l] * kTrainCin[l] * 9);
@@ -1710,12 +1710,14 @@ static void train_allow_lds(K kernel)
     if (train_lds_pad()) (void)hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)train_lds_pad());
 }
 
-template <int BN, int MODE>
+template <int BN, int MODE, bool CS4 = false>
 static void launch_conv_gemm(hipStream_t s, const ConvGemmArgs &a)
 {
-    static const bool once = (train_allow_lds(conv_gemm_kernel<BN, MODE>), true);
+    static const bool once = (train_allow_lds(conv_gemm_kernel<BN, MODE, CS4>), true);
     (void)once;
-    hipLaunchKernelGGL((conv_gemm_kernel<BN, MODE>), dim3((a.M + TBM - 1) / TBM, (a.N + BN - 1) / BN), dim3(256), train_lds_pad(), s, a);
+    // (the kernel's stage arithmetic: 4 source channels, or a multiple of the 16 k of a stage)
+    if (CS4 ? a.Cs != 4 : a.Cs % TKC != 0) { fprintf(stderr, "azgomoku: conv_gemm_kernel cannot take %d source channels\n", a.Cs); abort(); }
+    hipLaunchKernelGGL((conv_gemm_kernel<BN, MODE, CS4>), dim3((a.M + TBM - 1) / TBM, (a.N + BN - 1) / BN), dim3(256), train_lds_pad(), s, a);
 }
 
 // forward pass of the batch already at w.x4 (channels-last) up to the head outputs hp / hv
@@ -1728,7 +1730,7 @@ static void train_forward_convs(azg_handle *h, int n, const TrainParams &P)
     ConvGemmArgs a{};
     a.M = M; a.S = S; a.Nb = N; a.taps = 9;
     a.src = w.x4; a.Cs = 4; a.K = 36; a.w = w.im.wf[0]; a.bias = P.p[1]; a.out = w.a[0]; a.N = 32; a.ldo = 32;
-    launch_conv_gemm<32, 0>(s, a);
+    launch_conv_gemm<32, 0, true>(s, a);
     a.src = w.a[0]; a.Cs = 32; a.K = 288; a.w = w.im.wf[1]; a.bias = P.p[3]; a.out = w.a[1]; a.N = 64; a.ldo = 64;
     launch_conv_gemm<64, 0>(s, a);
     a.src = w.a[1]; a.Cs = 64; a.K = 576; a.w = w.im.wf[2]; a.bias = P.p[5]; a.out = w.a[2]; a.N = 128; a.ldo = 128;
@@ -1749,9 +1751,11 @@ static FcArgs train_fc_args(azg_handle *h, int n, const TrainParams &P)
 }
 
 extern "C" int azg_train_forward(azg_handle *h, int n, const float *states, const float *const params[16], float *probs,
-                                 float *values)
+                                 float *values, const float *old_probs, double *kl)
 {
-    if (!h || n < 0 || !states || !probs || !values) return fail(h, AZG_EINVAL, "null argument");
+    if (!h || n < 0 || !states || !probs || !values || (old_probs && !kl)) return fail(h, AZG_EINVAL, "null argument");
+    if (old_probs && !is_device_ptr(old_probs)) return fail(h, AZG_EINVAL, "azg_train_forward takes device pointers");
+    if (kl) *kl = 0.0;
     if (n == 0) return AZG_OK;
     HIPCHK(h, hipSetDevice(h->cfg.device));
     int rc = train_check_ptrs(h, params);
@@ -1767,8 +1771,14 @@ extern "C" int azg_train_forward(azg_handle *h, int n, const float *states, cons
     FcArgs f = train_fc_args(h, n, P);
     f.probs = probs; f.values = values;
     hipLaunchKernelGGL(fc_sample_kernel, dim3(n), dim3(256), 0, w.stream, f);
+    double *kl_dev = reinterpret_cast<double *>(w.lossout + 4), *kl_host = reinterpret_cast<double *>(w.h_loss + 2);
+    if (old_probs) {
+        hipLaunchKernelGGL(kl_kernel, dim3(1), dim3(1024), 0, w.stream, old_probs, (const float *)probs, n, h->st.S, kl_dev);
+        HIPCHK(h, hipMemcpyAsync(kl_host, kl_dev, 8, hipMemcpyDeviceToHost, w.stream));
+    }
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipStreamSynchronize(w.stream));
+    if (old_probs) *kl = *kl_host;
     return AZG_OK;
 }
 

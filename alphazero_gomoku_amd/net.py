@@ -220,24 +220,36 @@ class PolicyValueNet(object):
             self._ptr_cache = ((C.c_void_p * 16)(*[t.data_ptr() for t in ts]), ts)
         return self._ptr_cache
 
-    def policy_value_in_training(self, state_batch):
+    def policy_value_in_training(self, state_batch, old_probs=None):
         """(probs [B,S], value [B,1]) of a CUDA batch for the KL monitor inside policy_update, from the
         parameters as they are NOW (between two train steps of one update the search engine's packed
-        copy is not refreshed): the library's float32 forward pass, azg_train_forward."""
+        copy is not refreshed): the library's float32 forward pass, azg_train_forward.
+        With old_probs (CUDA f32 [B,S]) a third value: the KL test's number of train.py:189-193,
+        mean(sum(old * (log(old + 1e-10) - log(new + 1e-10)), 1)), summed in double."""
         st = state_batch.to(device=self.device, dtype=torch.float32).contiguous()
         if not self.native_train:
             with torch.no_grad():
                 logp, v = self.policy_value_net(st)
-            return torch.exp(logp), v.reshape(-1, 1)
+            probs = torch.exp(logp)
+            if old_probs is None:
+                return probs, v.reshape(-1, 1)
+            o = old_probs.double()
+            kl = float(torch.mean(torch.sum(o * (torch.log(o + 1e-10) - torch.log(probs.double() + 1e-10)), dim=1)))
+            return probs, v.reshape(-1, 1), kl
         n, s = int(st.shape[0]), self.board_width * self.board_height
         probs = torch.empty((n, s), dtype=torch.float32, device=self.device)
         vals = torch.empty(n, dtype=torch.float32, device=self.device)
         eng = self._engine_handle()
         arr, keep = self._param_ptrs()
+        old = None if old_probs is None else old_probs.to(device=self.device, dtype=torch.float32).contiguous()
+        kl = C.c_double(0.0)
         torch.cuda.current_stream(self.device).synchronize()
         eng._chk(eng.L.azg_train_forward(eng.h, n, C.c_void_p(st.data_ptr()), arr, C.c_void_p(probs.data_ptr()),
-                                         C.c_void_p(vals.data_ptr())))
-        return probs, vals.reshape(-1, 1)
+                                         C.c_void_p(vals.data_ptr()), C.c_void_p(old.data_ptr()) if old is not None else None,
+                                         C.byref(kl) if old is not None else None))
+        if old is None:
+            return probs, vals.reshape(-1, 1)
+        return probs, vals.reshape(-1, 1), float(kl.value)
 
     def policy_value_fn(self, board):
         """policy_value_net_pytorch.py:96-115: (zip(legal moves, probs), value)."""

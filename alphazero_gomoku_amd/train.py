@@ -198,12 +198,15 @@ class TrainPipeline:
         return idx
 
     def policy_update(self):
+        import time
         import torch
+        t_begin = time.perf_counter()
         state_batch, mcts_probs_batch, winner_batch = self.data_buffer.take(self._draw())
         net = self.policy_value_net
         on_device = torch.is_tensor(state_batch)
-        # (device batches: the KL monitor reads the autograd module, see policy_value_in_training)
-        policy_value = getattr(net, "policy_value_in_training", net.policy_value) if on_device else net.policy_value
+        # (device batches: the KL monitor's forward pass, and its sum, run in the library: policy_value_in_training)
+        with_kl = on_device and hasattr(net, "policy_value_in_training")
+        policy_value = net.policy_value_in_training if with_kl else net.policy_value
         old_probs, old_v = policy_value(state_batch)
         sl = slice(self.rank, None, self.world)                               # this rank's share of the mini-batch
         kl, loss, entropy = 0.0, float("nan"), float("nan")
@@ -211,12 +214,15 @@ class TrainPipeline:
         for _ in range(self.epochs):
             loss, entropy = net.train_step(state_batch[sl], mcts_probs_batch[sl], winner_batch[sl],
                                            self.learn_rate * self.lr_multiplier)
-            new_probs, new_v = policy_value(state_batch)
-            if on_device:
-                kl = float(torch.mean(torch.sum(old_probs.double() * (torch.log(old_probs.double() + 1e-10)
-                                                                      - torch.log(new_probs.double() + 1e-10)), dim=1)))
+            if with_kl:
+                new_probs, new_v, kl = policy_value(state_batch, old_probs)
             else:
-                kl = float(np.mean(np.sum(old_probs * (np.log(old_probs + 1e-10) - np.log(new_probs + 1e-10)), axis=1)))
+                new_probs, new_v = policy_value(state_batch)
+                if on_device:
+                    kl = float(torch.mean(torch.sum(old_probs.double() * (torch.log(old_probs.double() + 1e-10)
+                                                                          - torch.log(new_probs.double() + 1e-10)), dim=1)))
+                else:
+                    kl = float(np.mean(np.sum(old_probs * (np.log(old_probs + 1e-10) - np.log(new_probs + 1e-10)), axis=1)))
             kl = self._agree(kl)
             if kl > self.kl_targ * 4:                                         # early stopping if D_KL diverges badly
                 break
@@ -224,16 +230,27 @@ class TrainPipeline:
             self.lr_multiplier /= 1.5
         elif kl < self.kl_targ / 2 and self.lr_multiplier < getattr(self, "max_lr_multiplier", 10.0):
             self.lr_multiplier *= 1.5
-        wz = winner_batch.double().cpu().numpy() if on_device else np.array(winner_batch)
-        ov = old_v.double().cpu().numpy().flatten() if on_device else old_v.flatten()
-        nv = new_v.double().cpu().numpy().flatten() if on_device else new_v.flatten()
-        var_z = np.var(wz)
-        self.explained_var_old = 1 - np.var(wz - ov) / var_z if var_z > 0 else float("nan")
-        self.explained_var_new = 1 - np.var(wz - nv) / var_z if var_z > 0 else float("nan")
+        # (explained variances, train.py:203-208: printed by the reference, read by nothing; computed when asked for)
+        self._explained = (winner_batch, old_v, new_v)
         self.last_kl = kl
         self.policy_updates += 1
+        # (host clock around the whole update; the KL value read above has waited for the device)
+        self.update_seconds = getattr(self, "update_seconds", 0.0) + time.perf_counter() - t_begin
         self.__dict__.setdefault("loss_history", []).append((loss, entropy))
         return loss, entropy
+
+    def _explained_var(self, which):
+        winner_batch, old_v, new_v = self._explained
+        v = (old_v, new_v)[which]
+        if hasattr(winner_batch, "double"):
+            wz, pv = winner_batch.double().cpu().numpy(), v.double().cpu().numpy().flatten()
+        else:
+            wz, pv = np.array(winner_batch), np.asarray(v).flatten()
+        var_z = np.var(wz)
+        return 1 - np.var(wz - pv) / var_z if var_z > 0 else float("nan")
+
+    explained_var_old = property(lambda self: self._explained_var(0))
+    explained_var_new = property(lambda self: self._explained_var(1))
 
     def _agree(self, kl):
         """Every rank must take the same early-stop and multiplier decisions (the train steps hold
@@ -426,6 +443,8 @@ def main(argv=None):
         losses = [l for l, _ in tp.loss_history]
         print(json.dumps({"games": tp.games_played, "ranks": world, "seconds": dt, "games_per_s_incl_training": tp.games_played / dt,
                           "samples": int(sum(n for _, n, _, _ in log)), "policy_updates": tp.policy_updates,
+                          "policy_update_ms_mean": (1e3 * getattr(tp, "update_seconds", 0.0) / tp.policy_updates
+                                                    if tp.policy_updates else None),
                           "updates_per_batch": upb, "play_batch": args.play_batch, "continuous": bool(args.continuous),
                           "slots_per_gpu": tp.engine.B, "rehearsal_on_one_gpu": bool(args.rehearse_on_one_gpu),
                           "trees_moved_to_large_arena": tp.engine.arena_stats()[0], "trees_dropped_for_lack_of_one": tp.engine.arena_stats()[1],

@@ -250,14 +250,17 @@ int azg_equi_data(azg_handle *h, int n, const float *states, const double *pi, c
  *                       parameters in place from that vector; adam_m / adam_v are the caller's moment
  *                       vectors (zero before step 1), step counts from 1;
  *   azg_train_forward   the forward pass alone: probs = exp(log_softmax) [n,S] and values [n], what
- *                       PolicyValueNet.policy_value (:80-94) gives for the KL test of train.py:187-201.
+ *                       PolicyValueNet.policy_value (:80-94) gives for the KL test of train.py:187-201;
+ *                       with old_probs (device f32 [n,S], else NULL) also that test's number in *kl:
+ *                       mean_n sum_a old * (log(old + 1e-10) - log(new + 1e-10)), summed in double
+ *                       (train.py:189-193);
  * states f32 [n,4,N,N], mcts_probs f32 [n,S], winners f32 [n], params: the 16 tensors of
  * policy_value_net_pytorch.py:31-41 in PyTorch's layout; ALL of these, grads, adam_m, adam_v, probs and
  * values are DEVICE pointers.  The calls run on a stream of their own (not behind a search in flight)
  * and are synchronous on return. */
 int azg_train_param_count(azg_handle *h);
 int azg_train_forward(azg_handle *h, int n, const float *states, const float *const params[16],
-                      float *probs, float *values);
+                      float *probs, float *values, const float *old_probs, double *kl);
 int azg_train_backward(azg_handle *h, int n, const float *states, const float *mcts_probs,
                        const float *winners, const float *const params[16], float *grads,
                        float *loss, float *entropy);
