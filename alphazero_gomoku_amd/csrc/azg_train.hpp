@@ -456,6 +456,8 @@ struct FcArgs {
     const float *wv2, *bv2;          // val_fc2 [64], [1]
     const float *pi, *z;             // targets [n][S], [n]  (null: forward only)
     float *probs, *values;           // forward-only outputs [n][S], [n] (may be null)
+    const float *oldp;               // [n][S] or null: earlier probabilities for the KL test of train.py:189-193
+    double *klparts;                 // [n]: sum_o oldp * (log(oldp + 1e-10) - log(probs + 1e-10)) of the sample
     float *dlogit, *dh1;             // [n][Sp] (Sp = S rounded up to 4, padding zero), [n][64]
     float *g2;                       // [n][128]: columns 0-63 dpre2 * h1[j] (val_fc2's weight gradient terms), 64 dpre2, rest zero
     float *dh8;                      // [n*S][8]: gradient at the six head pre-activations, channels-last
@@ -521,6 +523,21 @@ __global__ __launch_bounds__(256) void fc_sample_kernel(FcArgs a)
     if (a.probs)
         for (int o = tid; o < S; o += 256) a.probs[(size_t)b * S + o] = expf((lg[o] - mx) - lse);
     if (a.values && tid == 0) a.values[b] = value;
+    if (a.oldp) {
+        __shared__ double dred[256];
+        double s = 0.0;
+        for (int o = tid; o < S; o += 256) {
+            const double old = a.oldp[(size_t)b * S + o], now = expf((lg[o] - mx) - lse);
+            s += old * (log(old + 1e-10) - log(now + 1e-10));
+        }
+        dred[tid] = s;
+        __syncthreads();
+        for (int w = 128; w > 0; w >>= 1) {
+            if (tid < w) dred[tid] += dred[tid + w];
+            __syncthreads();
+        }
+        if (tid == 0) a.klparts[b] = dred[0];
+    }
     if (!a.pi) return;
 
     // losses of the sample and the gradient at the logits: d(-mean_b sum_o pi log p)/dlogit = (p * sum(pi) - pi) / n
@@ -672,20 +689,17 @@ __global__ __launch_bounds__(256) void loss_kernel(const float *parts, int n, fl
 // torch.optim.Adam (weight_decay added to the gradient, no amsgrad) on the flat state:
 //   g += wd * p;  m = m + (1 - b1) * (g - m);  v = b2 * v + ((1 - b2) * g) * g;
 //   p += (-(lr / (1 - b1^t)) * m) / (sqrt(v) / sqrt(1 - b2^t) + eps)        (the operation order of its float32 kernels)
-// The KL test of train.py:187-193: mean over the batch of sum_a old * (log(old + 1e-10) - log(new + 1e-10)),
+// The KL test of train.py:187-193: mean over the batch of the samples' sums (fc_sample_kernel's klparts),
 // in double, summed in a fixed order (one workgroup).
-__global__ __launch_bounds__(1024) void kl_kernel(const float *oldp, const float *newp, int n, int S, double *out)
+__global__ __launch_bounds__(256) void kl_kernel(const double *parts, int n, double *out)
 {
-    __shared__ double red[1024];
-    const int tid = threadIdx.x, total = n * S;
+    __shared__ double red[256];
+    const int tid = threadIdx.x;
     double s = 0.0;
-    for (int i = tid; i < total; i += 1024) {
-        const double o = oldp[i], q = newp[i];
-        s += o * (log(o + 1e-10) - log(q + 1e-10));
-    }
+    for (int i = tid; i < n; i += 256) s += parts[i];
     red[tid] = s;
     __syncthreads();
-    for (int w = 512; w > 0; w >>= 1) {
+    for (int w = 128; w > 0; w >>= 1) {
         if (tid < w) red[tid] += red[tid + w];
         __syncthreads();
     }

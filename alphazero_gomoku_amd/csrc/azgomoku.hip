@@ -212,7 +212,8 @@ struct azg_handle {
         float *ppart = nullptr, *pbpart = nullptr, *vpart = nullptr, *vbpart = nullptr, *g2part = nullptr;
         int wsplits[3] = {0}, wrows[3] = {0}, hsplits = 0, hrows = 0, fsplits = 0, frows = 0, gsplits = 0, grows = 0;
         const float *checked[16] = {nullptr};    // parameter pointers already seen to be device memory
-        float *h_loss = nullptr;                 // pinned [2]
+        float *h_loss = nullptr;                 // pinned: loss, entropy, and a double (KL) at +8
+        double *klparts = nullptr;               // [n] per-sample sums of the KL test
     } tw;
     // profiling
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
@@ -1658,7 +1659,7 @@ static int train_prepare(azg_handle *h, int n)
     const size_t o_d0 = take(Mz * 32), o_d1 = take(Mz * 64), o_d2 = take(Mz * 128);
     const size_t o_hp = take((size_t)n * 4 * S), o_hv = take((size_t)n * ldhv), o_dh8 = take(Mz * 8);
     const size_t o_dl = take((size_t)n * Sp), o_dh1 = take((size_t)n * 64), o_g2 = take((size_t)n * 128);
-    const size_t o_lp = take((size_t)n * 3), o_lo = take(8);   // lossout: loss, entropy, -, -, a double (KL)
+    const size_t o_lp = take((size_t)n * 3), o_klp = take((size_t)n * 2), o_lo = take(8);   // lossout: loss, entropy, -, -, a double (KL)
     size_t o_wf[3], o_wd[3], o_wp[3], o_bp[3];
     for (int l = 0; l < 3; l++) {
         o_wf[l] = take((size_t)kTrainCout[l] * kTrainCin[l] * 9);
@@ -1676,7 +1677,7 @@ static int train_prepare(azg_handle *h, int n)
     w.x4 = at(o_x4); w.a[0] = at(o_a0); w.a[1] = at(o_a1); w.a[2] = at(o_a2);
     w.dz[0] = at(o_d0); w.dz[1] = at(o_d1); w.dz[2] = at(o_d2);
     w.hp = at(o_hp); w.hv = at(o_hv); w.dh8 = at(o_dh8); w.dlogit = at(o_dl); w.dh1 = at(o_dh1); w.g2 = at(o_g2);
-    w.lossparts = at(o_lp); w.lossout = at(o_lo);
+    w.lossparts = at(o_lp); w.lossout = at(o_lo); w.klparts = reinterpret_cast<double *>(at(o_klp));
     for (int l = 0; l < 3; l++) { w.im.wf[l] = at(o_wf[l]); w.im.wd[l] = at(o_wd[l]); w.wpart[l] = at(o_wp[l]); w.bpart[l] = at(o_bp[l]); }
     w.im.wh = at(o_wh); w.im.bh = at(o_bh); w.hpart = at(o_hpt); w.hbpart = at(o_hbp);
     w.ppart = at(o_pp); w.pbpart = at(o_pbp); w.vpart = at(o_vp); w.vbpart = at(o_vbp); w.g2part = at(o_g2p);
@@ -1769,11 +1770,11 @@ extern "C" int azg_train_forward(azg_handle *h, int n, const float *states, cons
     hipLaunchKernelGGL(planes_to_rows_kernel, dim3((M + 255) / 256), dim3(256), 0, w.stream, states, n, h->st.S, w.x4);
     train_forward_convs(h, n, P);
     FcArgs f = train_fc_args(h, n, P);
-    f.probs = probs; f.values = values;
+    f.probs = probs; f.values = values; f.oldp = old_probs; f.klparts = w.klparts;
     hipLaunchKernelGGL(fc_sample_kernel, dim3(n), dim3(256), 0, w.stream, f);
     double *kl_dev = reinterpret_cast<double *>(w.lossout + 4), *kl_host = reinterpret_cast<double *>(w.h_loss + 2);
     if (old_probs) {
-        hipLaunchKernelGGL(kl_kernel, dim3(1), dim3(1024), 0, w.stream, old_probs, (const float *)probs, n, h->st.S, kl_dev);
+        hipLaunchKernelGGL(kl_kernel, dim3(1), dim3(256), 0, w.stream, (const double *)w.klparts, n, kl_dev);
         HIPCHK(h, hipMemcpyAsync(kl_host, kl_dev, 8, hipMemcpyDeviceToHost, w.stream));
     }
     HIPCHK(h, hipGetLastError());

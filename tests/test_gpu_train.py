@@ -68,6 +68,12 @@ def test_native_gradients_match_autograd(az, n, batch):
     assert off == grad.numel()
     probs, vals = net.policy_value_in_training(torch.as_tensor(s, device=net.device))
     assert float((probs - torch.exp(logp32)).abs().max()) < 1e-6 and float((vals - v32).abs().max()) < 1e-6
+    # the KL test's number (train.py:189-193) against the same formula in float64; old = a perturbed copy
+    old = torch.softmax(torch.log(probs) + 0.3 * torch.randn_like(probs), dim=1).contiguous()
+    probs_again, _, kl = net.policy_value_in_training(torch.as_tensor(s, device=net.device), old)
+    o, q = old.double(), probs.double()
+    want = float(torch.mean(torch.sum(o * (torch.log(o + 1e-10) - torch.log(q + 1e-10)), dim=1)))
+    assert torch.equal(probs, probs_again) and abs(kl - want) <= 1e-12 + 1e-9 * abs(want), (kl, want)
     # and it is the same bits every time
     grad2, loss2, ent2 = net.native_gradients(s, pi, z)
     assert torch.equal(grad, grad2) and loss == loss2 and ent == ent2
