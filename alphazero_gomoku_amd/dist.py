@@ -6,6 +6,8 @@ games with id = r, r + world, r + 2*world, ... and game id g always uses seed se
 which makes the set of games independent of the number of ranks.  The only exchange is
 the variable-length gather of training tuples: an all_gather of the per-rank counts,
 then one padded all_gather per tensor."""
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -19,7 +21,9 @@ def shard_game_ids(rank, world, n_games_total):
 def _comm_device(dev, group=None):
     """Device the collectives' buffers live on: the tensors' own (RCCL moves GPU memory directly),
     the host under the gloo backend (CPU tests; rehearsals of several ranks on one GPU)."""
-    return torch.device("cpu") if dist.get_backend(group) == "gloo" else dev
+    if dist.get_backend(group) == "gloo" and os.environ.get("AZG_GLOO_DEVICE_TENSORS") != "1":   # (=1: diagnostic only)
+        return torch.device("cpu")
+    return dev
 
 
 def gather_samples(tensors, group=None):

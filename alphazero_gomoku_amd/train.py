@@ -10,7 +10,10 @@ file; policy_evaluate plays the rollout opponent only (the external Yixin engine
 train.py:231-245 is not supported).
 With torch.distributed initialised every rank plays its share of the games, all ranks gather all
 tuples, and a policy update is one data-parallel step (each rank its slice of the mini-batch)."""
+import os
 import random
+import sys
+import time
 
 import numpy as np
 
@@ -125,7 +128,8 @@ class TrainPipeline:
         """Continuous mode: one pending policy update per move step, issued while the next search
         (already enqueued by the step) runs; after the last one the engine gets the new weights."""
         if self._todo:
-            if self.world > 1:
+            # (AZG_UPDATES_BESIDE_SEARCH=1: diagnostic, the single-GPU schedule with several ranks as well)
+            if self.world > 1 and os.environ.get("AZG_UPDATES_BESIDE_SEARCH") != "1":
                 # Data-parallel updates hold collectives, and a collective's kernel gets no CU while a
                 # search launch is resident (two workgroups per CU fill the LDS and the registers): every
                 # one of the ~11 collectives of an update would wait for the end of a search.  So with
@@ -177,6 +181,11 @@ class TrainPipeline:
             s = {k: empty[k] for k in keys}
         if self.world > 1:
             from . import dist as azdist
+            if self.continuous:
+                # The move step above has already enqueued the next search.  A collective's kernel gets no CU
+                # beside a resident search launch, and every rank's would then wait for every other rank's
+                # search: let the one in flight finish first (once per batch of games).
+                torch.cuda.synchronize(dev)
             s = azdist.gather_packed(s, self.board_width * self.board_height)
             s["states"] = self.engine.unpack_states(s["stones"], s["last"], s["ply"])
         order = torch.argsort(s["game_id"] * 1024 + s["ply"].to(torch.int64))   # game after game, ply after ply
@@ -338,6 +347,35 @@ class TrainPipeline:
         return self.policy_value_net
 
 
+def _hang_watchdog(seconds, rank, device):
+    """Diagnostic (AZG_HANG_WATCHDOG=seconds in the environment): if the run is still going after that
+    long, every thread's Python stack goes to stderr, then a helper thread waits for the device: if ALL
+    work this process has enqueued on the GPU completes, the run is stuck on the host side (it says how
+    long the wait took); if that wait does not come back within 20 s it is stuck on the device.  The
+    process then exits with status 3."""
+    import faulthandler
+    import threading
+
+    def watch():
+        time.sleep(seconds)
+        print("[watchdog rank %d] still running after %.0f s; stacks:" % (rank, seconds), file=sys.stderr, flush=True)
+        faulthandler.dump_traceback(file=sys.stderr, all_threads=True)
+        done = threading.Event()
+
+        def wait_for_device():
+            import torch
+            t = time.perf_counter()
+            torch.cuda.synchronize(device)
+            print("[watchdog rank %d] all device work of this process completed (waited %.3f s): stuck on the host side"
+                  % (rank, time.perf_counter() - t), file=sys.stderr, flush=True)
+            done.set()
+        threading.Thread(target=wait_for_device, daemon=True).start()
+        if not done.wait(20.0):
+            print("[watchdog rank %d] device work still pending after 20 s: stuck on the device" % rank, file=sys.stderr, flush=True)
+        os._exit(3)
+    threading.Thread(target=watch, daemon=True).start()
+
+
 def main(argv=None):
     """The training loop as a program: `python -m alphazero_gomoku_amd.train --games 3000` on one
     GPU, or under `python -m torch.distributed.run --nproc-per-node N` with one rank per GPU
@@ -422,6 +460,8 @@ def main(argv=None):
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
+    if os.environ.get("AZG_HANG_WATCHDOG"):
+        _hang_watchdog(float(os.environ["AZG_HANG_WATCHDOG"]), rank, local)
     log = []
     t0 = time.perf_counter()
     def on_batch(i, n_samples, loss, ent):
