@@ -170,6 +170,21 @@ def visit_l1_vs_cpu(az, az_oracle, n, k, n_playout, params, params_np, samples, 
             "note": "fresh-root searches from positions of the timed run's games; CPU side = oracle tree + its float64 net"}
 
 
+def trained_params(path, n, device):
+    """The 16 parameter tensors (state_dict order, PyTorch layout) of a trained net for an n x n board, or None
+    when `path` holds none for that size."""
+    import numpy as np
+    import torch
+    if path.endswith(".npz"):
+        with np.load(path) as d:
+            if "params_%d_0" % n not in d.files:
+                return None
+            return [torch.from_numpy(np.ascontiguousarray(d["params_%d_%d" % (n, i)])).to(device) for i in range(16)]
+    import alphazero_gomoku_amd as az
+    net = az.PolicyValueNet(n, n, model_file=path, device=device.index or 0)
+    return [t.detach().clone() for t in net.param_tensors()]
+
+
 def _free_port():
     import socket
     with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
@@ -268,6 +283,11 @@ def main():
                     help="expanded nodes a game's tree arena holds (0 = the library's default, 16 searches' worth when memory allows)")
     ap.add_argument("--cnn", choices=["f16x3", "f32"], default="f16x3",
                     help="conv arithmetic: split-f16 MFMA (three products, f32 accumulate) or f32-input MFMA")
+    ap.add_argument("--model", default=None,
+                    help="weights of a TRAINED net for the second, shorter measurement reported as `trained_net` (deep, narrow "
+                         "trees: the descent-bound regime): an .npz holding params_<board>_<0..15> in PyTorch's layout, or a "
+                         "state_dict file; default tests/golden/g10_trained.npz when it holds this board size; 'none' skips it")
+    ap.add_argument("--trained-steps", type=int, default=48, help="timed move steps of the trained-net measurement")
     args = ap.parse_args()
 
     under_launcher = "RANK" in os.environ
@@ -466,6 +486,39 @@ def main():
             out["roofline_tree_side"] = {"bound": "hbm", "achieved": hbm, "peak": 8000.0, "unit": "GB/s", "frac": hbm / 8000.0,
                                          "note": "same kernel; %.1f KB of tree/board traffic per playout, latency-bound "
                                                  "pointer chasing inside the fused launch" % (tree_bytes / 1e3)}
+        # The same workload with a TRAINED net: sharp priors make deep, narrow trees, the regime in which
+        # the descent (not the leaf CNN) bounds a launch.  Own pre-roll, own timed region, one GPU only.
+        model = args.model or os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden", "g10_trained.npz")
+        if world == 1 and model != "none" and os.path.exists(model):
+            tparams = trained_params(model, n, dev)
+            if tparams is not None:
+                eng.set_weights(tparams)
+                run2 = SelfPlayRunner(eng, temp=1.0, seed0=1 << 20, first_game_id=0, game_id_stride=1, total=None,
+                                      on_samples=lambda chunk: None, device_samples=True, pipelined=not args.host_refill)
+                run2.start()
+                pre2 = 0
+                while pre2 < args.preroll_max:
+                    run2.step()
+                    pre2 += 1
+                    if run2.games_delivered >= 2 * args.games and pre2 >= 3.0 * run2.plies_done / run2.games_delivered:
+                        break
+                eng.profile()
+                torch.cuda.synchronize()
+                g2, t2 = run2.games_done, time.perf_counter()
+                for _ in range(args.trained_steps):
+                    run2.step()
+                torch.cuda.synchronize()
+                dt2 = time.perf_counter() - t2
+                run2.finish()
+                l2, k2, e2 = eng.profile()
+                ach2 = flop * e2 / (k2 * 1e-3) / 1e12 if k2 > 0 else 0.0
+                out["trained_net"] = {"model": os.path.relpath(model, os.path.dirname(os.path.abspath(__file__))),
+                                      "steps": args.trained_steps, "preroll_steps": pre2,
+                                      "ms_per_step": dt2 / args.trained_steps * 1e3, "value": (run2.games_done - g2) / dt2,
+                                      "unit": "games/s", "avg_launch_ms": k2 / l2 if l2 else None,
+                                      "plies_per_game": run2.plies_done / run2.games_delivered if run2.games_delivered else None,
+                                      "roofline_frac": ach2 / PEAK_TFLOPS[args.cnn]}
+                eng.set_weights(params)
         if world == 1 and not args.no_cpu_baseline:
             params_np = [p.cpu().numpy() for p in params]
             out["cpu_baseline"] = cpu_baseline(n, k, args.playouts, params_np, plies_per_game)

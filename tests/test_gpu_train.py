@@ -469,3 +469,64 @@ def test_batched_training_loop_learns(az):
     s, p, z = tp.data_buffer.take(tp.data_buffer.draw(256))
     probs, v = tp.policy_value_net.policy_value(s)
     assert float(probs.std(0).mean()) > 1e-3 and float(v.std()) > 1e-2      # not a constant function
+
+
+def _native_dp_worker(rank, world, port, q):
+    import os
+    import torch
+    import torch.distributed as dist
+    import alphazero_gomoku_amd as pkg
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        net = pkg.PolicyValueNet(8, 8, device=0)
+        net.load_numpy_params(helpers.make_params(8, seed=41))
+        net.data_parallel = True
+        s, pi, z = _dp_batch()
+        sl = slice(rank, None, world)                          # this rank's share, as TrainPipeline.policy_update slices it
+        out = [net.train_step(torch.as_tensor(s[sl], device="cuda:0"), torch.as_tensor(pi[sl], device="cuda:0"),
+                              torch.as_tensor(z[sl], device="cuda:0"), 2e-3) for _ in range(2)]
+        q.put((rank, out, [t.detach().cpu().numpy() for t in net.param_tensors()]))
+    finally:
+        dist.destroy_process_group()
+
+
+def _dp_batch():
+    rs = np.random.RandomState(77)
+    s = (rs.rand(64, 4, 8, 8) < 0.3).astype(np.float32)
+    pi = rs.dirichlet(np.full(64, 0.3), size=64).astype(np.float32)
+    z = rs.choice([-1.0, 0.0, 1.0], size=64).astype(np.float32)
+    return s, pi, z
+
+
+def test_native_data_parallel_step_two_ranks_on_one_gpu(az):
+    """Two ranks on GPU 0 (gloo, gradients staged through the host), each with its share of a mini-batch:
+    azg_train_backward, ONE all_reduce of the flat gradient vector, azg_train_adam.  After two steps
+    both ranks hold the same parameters, and they equal a single process's two steps on the whole
+    mini-batch (policy_value_net_pytorch.py:117-148) to float32 rounding."""
+    import os
+    import torch
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 32500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_native_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    try:
+        res = sorted((q.get(timeout=240) for _ in range(2)), key=lambda t: t[0])
+    finally:
+        for p in procs:
+            p.join(timeout=60)
+            if p.is_alive():
+                p.kill()
+    net = az.PolicyValueNet(8, 8, device=0)
+    net.load_numpy_params(helpers.make_params(8, seed=41))
+    s, pi, z = _dp_batch()
+    for _ in range(2):
+        net.train_step(torch.as_tensor(s, device="cuda:0"), torch.as_tensor(pi, device="cuda:0"), torch.as_tensor(z, device="cuda:0"), 2e-3)
+    want = [t.detach().cpu().numpy() for t in net.param_tensors()]
+    for a, b, w in zip(res[0][2], res[1][2], want):
+        assert np.array_equal(a, b)
+        np.testing.assert_allclose(a, w, rtol=0, atol=3e-6)
