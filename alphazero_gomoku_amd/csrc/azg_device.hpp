@@ -232,20 +232,31 @@ struct Prof {
     // s_getreg operands: id | offset << 6 | (width - 1) << 11
     static constexpr int GETREG_HW_ID = 4 | (0 << 6) | (31 << 11), GETREG_XCC_ID = 20 | (0 << 6) | (3 << 11);
     long long *out; long long last, t0, r0; bool on;
-    unsigned acc[20];
+    unsigned acc[28];
     __device__ void start(long long *o, int tid_on = 0)
     {
         out = o; on = o != nullptr && (int)threadIdx.x == tid_on;
-        for (int i = 0; i < 20; i++) acc[i] = 0;
+        for (int i = 0; i < 28; i++) acc[i] = 0;
         last = t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime();
     }
     __device__ void mark(int i) { if (on) { const long long now = __builtin_amdgcn_s_memtime(); acc[i] += (unsigned)(now - last); last = now; } }
     __device__ void count(int i, int v) { if (on) acc[i] += (unsigned)v; }      // a plain counter in slot i
+    // a mark that waits until the vector value `dep` exists (the clock is read by a scalar instruction,
+    // which the compiler and the hardware would otherwise let overtake the arithmetic it is meant to follow)
+    __device__ void mark_after(int i, int dep)
+    {
+        if (on) {
+            asm volatile("s_nop 0" :: "v"(dep) : "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            mark(i);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
     // slots 30 / 31: shader cycles and 100 MHz ticks of the whole loop (their ratio is the clock held)
     __device__ void finish()
     {
         if (!on) return;
-        for (int i = 0; i < 20; i++) atomicAdd((unsigned long long *)&out[i], (unsigned long long)acc[i]);
+        for (int i = 0; i < 28; i++) atomicAdd((unsigned long long *)&out[i], (unsigned long long)acc[i]);
         atomicAdd((unsigned long long *)&out[30], (unsigned long long)(__builtin_amdgcn_s_memtime() - t0));
         const unsigned long long rt = (unsigned long long)(__builtin_amdgcn_s_memrealtime() - r0);
         atomicAdd((unsigned long long *)&out[31], rt);
@@ -258,6 +269,7 @@ struct Prof {
     __device__ void start(long long *, int = 0) {}
     __device__ void mark(int) {}
     __device__ void count(int, int) {}
+    __device__ void mark_after(int, int) {}
     __device__ void finish() {}
 #endif
 };

@@ -118,7 +118,7 @@ __device__ __forceinline__ void search_body(DevState st)
         if (active) {
             const TreeView tv = tree_view(st, g, gl->arena, gl->big);
             if constexpr (MODE == 0 && N * N <= WAVE && AZG_SPEC_LEVELS > 0) d = wave_select_spec<GL>(st, tv, gl, lane);
-            else d = wave_select<GL, false, (MODE == 0 ? (N * N + WAVE - 1) / WAVE : MAXS / WAVE)>(st, tv, gl, lane);
+            else d = wave_select<GL, false, (MODE == 0 ? (N * N + WAVE - 1) / WAVE : MAXS / WAVE)>(st, tv, gl, lane, &prof);
             // (with n_in_row < 3 a line can exist before the reference's n_in_row + 2 stone threshold
             // lets it count, so it need not contain the last stone: full scan there)
             if (d.depth > 1 && st.n_in_row >= 3 && st.n_in_row <= 8)

@@ -262,6 +262,9 @@ __device__ inline int game_end_1w(u64 s1, u64 s2, int N, int S, int nrow, int ns
 #ifndef AZG_SELECT_SCREEN
 #define AZG_SELECT_SCREEN 1       // 0: every level takes the double-precision pass
 #endif
+#ifndef AZG_SELECT_REG_STONES
+#define AZG_SELECT_REG_STONES 1   // 0: lane 0 updates the leaf's stones in LDS on every level
+#endif
 #ifndef AZG_SELECT_PRIO
 // A descent that goes deep (a trained net: six path entries on average instead of three) holds up its
 // workgroup's whole playout iteration while the partner workgroup's dense loops, at priority 2, take
@@ -277,14 +280,26 @@ __device__ inline int game_end_1w(u64 s1, u64 s2, int N, int S, int nrow, int ns
 // for |Q| <= 1 and priors in [0, 1], which the engine's own providers guarantee; the descent that
 // serves a caller-evaluated playout (arbitrary values and priors) is instantiated without it.
 template <class GL, bool UNIFORM_P = false, int CPL = MAXS / WAVE, bool SCREEN = true>
-__device__ inline Descent wave_select(const DevState &st, const TreeView &t, GL *gl, int lane)
+__device__ inline Descent wave_select(const DevState &st, const TreeView &t, GL *gl, int lane, Prof *pf = nullptr)
 {
+    // (pf: phase timer of a diagnostic build, slots 20-23 per level: path record of the level above and
+    //  loop head / loads issued -> screen evaluated / double pass and argmax / hand-over of the chosen child)
     // (only the one-child-per-lane kernels, where the descent shares its SIMD with a partner workgroup's
     // dense loops; in the two-wave-group kernel of the larger boards it measured 2.5 % slower)
     constexpr bool RAISE = AZG_SELECT_PRIO > 0 && CPL == 1 && !UNIFORM_P;
     if (RAISE && AZG_SELECT_PRIO_LEVEL == 0) __builtin_amdgcn_s_setprio(AZG_SELECT_PRIO);
     // leaf board starts as a copy of the root board (copy.deepcopy, :162)
     if (lane < 2 * MAXW) ((u64 *)gl->leaf_bb)[lane] = ((u64 *)gl->root_bb)[lane];
+#if AZG_SELECT_REG_STONES
+    // The stones along the path are kept in registers (every lane the same words) and stored once at
+    // the leaf: a read-modify-write of the LDS copy by lane 0 on every level is a dependent LDS round
+    // trip per level, and so is re-reading who moves first.
+    constexpr int LW = CPL < MAXW ? CPL : MAXW;                  // stone words a board of this kernel has
+    u64 lb[2][LW];
+#pragma unroll
+    for (int w = 0; w < LW; w++) { lb[0][w] = gl->root_bb[0][w]; lb[1][w] = gl->root_bb[1][w]; }
+    const int first_player = gl->first_player;
+#endif
     wave_sync();
     int e = 0;                       // root edge
     int depth = 1;
@@ -299,6 +314,7 @@ __device__ inline Descent wave_select(const DevState &st, const TreeView &t, GL 
         double best = -HUGE_VAL, bq = 0.0;
         int bidx = 0x7fffffff, bchild = -1, bn = 0;
         unsigned bmeta = 0;
+        if (pf) pf->mark_after(20, depth);
         // a node has up to 64 * CPL children (CPL: the caller's bound, all boards: MAXS / WAVE), CPL
         // per lane: all of a lane's loads go out before the first is used (clamped index instead of
         // a guard), one memory round trip per level
@@ -352,6 +368,7 @@ __device__ inline Descent wave_select(const DevState &st, const TreeView &t, GL 
             }
             if (near == 1 && m32 < HUGE_VALF && m32 > -HUGE_VALF) ri_screen = at;
         }
+        if (pf) pf->mark_after(21, ri_screen);
         if (ri_screen < 0) {
         const double sq = sqrt((double)Np);                      // np.sqrt(parent._n_visits)
 #pragma unroll
@@ -386,6 +403,7 @@ __device__ inline Descent wave_select(const DevState &st, const TreeView &t, GL 
             // the index is kept inside the node's block whatever the scores are)
             ri = min(wave_min_i32(best == rs ? bidx : 0x7fffffff), K - 1);
         }
+        if (pf) pf->mark_after(22, ri);
         const int src = ri & 63;
         e = child + ri;
         child = __builtin_amdgcn_readlane(bchild, src);
@@ -394,7 +412,22 @@ __device__ inline Descent wave_select(const DevState &st, const TreeView &t, GL 
         const unsigned mt = (unsigned)__builtin_amdgcn_readlane((int)bmeta, src);
         K = meta_k(mt);
         const int act = meta_act(mt);
+        if (pf) pf->mark_after(23, (int)mt);
         // Board.do_move (game.py:119-127) on the leaf copy
+#if AZG_SELECT_REG_STONES
+        {
+            const int mover = player_at(first_player, ply);
+            const u64 bit = 1ULL << (act & 63);
+#pragma unroll
+            for (int w = 0; w < LW; w++)
+                if (w == (act >> 6)) { if (mover == 1) lb[0][w] |= bit; else lb[1][w] |= bit; }
+        }
+        if (lane == 0) {
+            gl->path[depth] = e;
+            gl->path_n[depth] = Np;
+            gl->path_q[depth] = qsel;
+        }
+#else
         if (lane == 0) {
             const int mover = player_at(gl->first_player, ply);
             gl->leaf_bb[mover - 1][act >> 6] |= 1ULL << (act & 63);
@@ -402,11 +435,18 @@ __device__ inline Descent wave_select(const DevState &st, const TreeView &t, GL 
             gl->path_n[depth] = Np;
             gl->path_q[depth] = qsel;
         }
+#endif
         depth++;
         ply++;
         last = act;
     }
-    if (lane == 0) { gl->depth = depth; gl->leaf = e; gl->leaf_ply = ply; gl->leaf_last = last; }
+    if (lane == 0) {
+        gl->depth = depth; gl->leaf = e; gl->leaf_ply = ply; gl->leaf_last = last;
+#if AZG_SELECT_REG_STONES
+#pragma unroll
+        for (int w = 0; w < LW; w++) { gl->leaf_bb[0][w] = lb[0][w]; gl->leaf_bb[1][w] = lb[1][w]; }
+#endif
+    }
     wave_sync();
     if (RAISE) __builtin_amdgcn_s_setprio(0);
     Descent d;

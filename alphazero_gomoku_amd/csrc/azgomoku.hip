@@ -179,6 +179,7 @@ struct azg_handle {
     char *h_mirror = nullptr;        // pinned
     char *d_mirror = nullptr;
     bool mirrors_fresh = false;
+    int search_parts = 0;                        // launches a move's playouts are spread over (AZG_SEARCH_PARTS; 0: the default of azg_search)
     size_t mirror_events = 0;        // profiling events recorded before the last mirror copy
     // pipelined self-play (azg_selfplay_*)
     struct Pipeline {
@@ -515,6 +516,9 @@ static int create_impl(azg_handle *h)
         // AZG_REROOT_COPY=1: every re-root copies the kept subtree (otherwise only when the arena runs low)
         const char *a = getenv("AZG_REROOT_COPY");
         st.rr_always = a && atoi(a) != 0;
+        // AZG_SEARCH_PARTS: launches a move's playouts are spread over (1 ... 8), see search_block
+        const char *sp = getenv("AZG_SEARCH_PARTS");
+        h->search_parts = sp ? std::max(1, std::min(64, atoi(sp))) : 0;    // (0: chosen below, once the kernel is known)
     }
     if (h->cfg.arena_nodes == 0) {
         // Default arena: room for the trees of 16 searches (8, 4 when memory is short).  A re-root
@@ -945,6 +949,16 @@ extern "C" int azg_set_position(azg_handle *h, int slot, const uint64_t stones1[
     return refresh_mirrors(h);
 }
 
+// launches a move's playouts are spread over
+static int search_parts_of(const azg_handle *h)
+{
+    int want = h->search_parts;
+    if (want <= 0) want = h->cfg.prior_mode != AZG_PRIOR_NET ? 1 : (h->cfg.board_n <= 8 ? 4 : 2);
+    return std::max(1, std::min(want, h->st.n_playout));
+}
+
+extern "C" int azg_search_parts(azg_handle *h) { return h ? search_parts_of(h) : AZG_EINVAL; }
+
 extern "C" int azg_search(azg_handle *h)
 {
     if (!h) return AZG_EINVAL;
@@ -962,7 +976,22 @@ extern "C" int azg_search(azg_handle *h)
     }
     auto &ev = h->ev_pool[h->ev_pending];
     HIPCHK(h, hipEventRecord(ev.first, h->stream));
-    hipLaunchKernelGGL(sl.fn, dim3(grid), dim3(sl.threads), sl.lds, h->stream, h->st);
+    // The playouts of the move in search_parts launches back to back.  Between two playouts the whole
+    // search state of a game is in global memory, so the trees do not depend on where the move is cut
+    // (all parity tests run with 1 and with 4 parts).  Measured, same box, interleaved rounds, 8x8 /
+    // 400 / 1024: 4 parts instead of 1: 11.40 -> 11.06 ms per move on one box, 10.98 -> 10.99 on another
+    // (the single launch varies between boxes, the split one does not); with a trained net 11.50 -> 11.05
+    // and 11.30 -> 10.72; 8 parts 11.07 / 10.89, 16 parts 11.13 / 11.0.  Dealing the games to other XCDs
+    // in every part changed nothing on top (every launch still ends with its slowest XCD).  15x15 / 800 /
+    // 512 (two-wave-group kernel): the search itself 43.6 -> 43.7 (2 parts) -> 44.0 ms (4), but the copy
+    // kernels of the noise upload, which find no room beside that kernel, slip in between two parts:
+    // move step - search 0.54 -> 0.14 ms, so 2 parts there.
+    const int parts = search_parts_of(h);
+    for (int p = 0; p < parts; p++) {
+        DevState part = h->st;
+        part.n_playout = h->st.n_playout / parts + (p < h->st.n_playout % parts ? 1 : 0);
+        hipLaunchKernelGGL(sl.fn, dim3(grid), dim3(sl.threads), sl.lds, h->stream, part);
+    }
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipEventRecord(ev.second, h->stream));
     h->ev_pending++;

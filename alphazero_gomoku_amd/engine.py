@@ -291,6 +291,10 @@ class SelfPlayEngine:
             None if planes is None else planes.ctypes.data_as(C.POINTER(C.c_float))))
         return ended.astype(bool), winner, planes
 
+    def search_parts(self):
+        """Kernel launches a move's playouts are spread over (azg_search_parts)."""
+        return int(self.L.azg_search_parts(self.h))
+
     def profile(self):
         """(search launches, summed ms on the engine's stream, summed leaf evaluations) since last call."""
         a, b, c = C.c_int64(0), C.c_double(0.0), C.c_int64(0)

@@ -172,15 +172,18 @@ def visit_l1_vs_cpu(az, az_oracle, n, k, n_playout, params, params_np, samples, 
 
 def trained_params(path, n, device):
     """The 16 parameter tensors (state_dict order, PyTorch layout) of a trained net for an n x n board, or None
-    when `path` holds none for that size."""
+    when `path` holds none for that size.  An .npz with params_<n>_<0..15> holds the reference's own model
+    files (mode/best_policy_*.model: Theano layout, kernels rotated, matrices as (in, out)), as the fixture
+    tests/golden/g10_trained.npz does; anything else is read as a model file of PolicyValueNet."""
     import numpy as np
     import torch
+    import alphazero_gomoku_amd as az
     if path.endswith(".npz"):
+        from alphazero_gomoku_amd.net import theano_to_torch_layout
         with np.load(path) as d:
             if "params_%d_0" % n not in d.files:
                 return None
-            return [torch.from_numpy(np.ascontiguousarray(d["params_%d_%d" % (n, i)])).to(device) for i in range(16)]
-    import alphazero_gomoku_amd as az
+            return [torch.from_numpy(a).to(device) for a in theano_to_torch_layout([d["params_%d_%d" % (n, i)] for i in range(16)])]
     net = az.PolicyValueNet(n, n, model_file=path, device=device.index or 0)
     return [t.detach().clone() for t in net.param_tensors()]
 
@@ -287,6 +290,9 @@ def main():
                     help="weights of a TRAINED net for the second, shorter measurement reported as `trained_net` (deep, narrow "
                          "trees: the descent-bound regime): an .npz holding params_<board>_<0..15> in PyTorch's layout, or a "
                          "state_dict file; default tests/golden/g10_trained.npz when it holds this board size; 'none' skips it")
+    ap.add_argument("--weights", default=None,
+                    help="run the MAIN measurement with these weights instead of the random-init net (same file forms as "
+                         "--model; for profiles of the trained-net regime: `value` is then NOT the headline configuration)")
     ap.add_argument("--trained-steps", type=int, default=48, help="timed move steps of the trained-net measurement")
     args = ap.parse_args()
 
@@ -344,6 +350,11 @@ def main():
 
     n, k = args.board, args.n_in_row
     params = random_init_params(n, dev)
+    if args.weights:
+        params = trained_params(args.weights, n, dev)
+        if params is None:
+            print("bench.py: %s holds no net for a %dx%d board" % (args.weights, n, n), file=sys.stderr)
+            sys.exit(2)
     eng = az.SelfPlayEngine(n, k, args.playouts, args.games, 5.0, device=local_rank, arena_nodes=args.arena_nodes,
                             cnn_mode=az._lib.CNN_F16X3 if args.cnn == "f16x3" else az._lib.CNN_F32)
     eng.set_weights(params)
@@ -453,9 +464,11 @@ def main():
             "dtype": "f16x3 (f32 operands split into two halves, three f16 MFMAs per product, f32 accumulate; tree in f64)" if args.cnn == "f16x3" else "f32",
             "data": "synthetic" + (" (REHEARSAL: all ranks share GPU 0, exchange over gloo -- not a measurement)" if args.rehearse_on_one_gpu else ""),
             "config": {"workload": "%dx%d board %d-in-row, n_playout=%d, %d parallel self-play games per MI355X, "
-                                   "random-init net (torch.manual_seed(0) default init), empty-board starts, "
+                                   "%s, empty-board starts, "
                                    "c_puct=5, temp=1, Dirichlet(0.1) mix 0.25, tree reuse, finished slots refilled"
-                                   % (n, n, k, args.playouts, args.games),
+                                   % (n, n, k, args.playouts, args.games,
+                                      "TRAINED net %s (not the headline configuration)" % args.weights if args.weights
+                                      else "random-init net (torch.manual_seed(0) default init)"),
                        "games_in_flight_per_gpu": args.games, "sharding": "game id mod n_gpus",
                        "step": "one move (n_playout playouts + sample/advance/re-root) for every slot"},
             "games_completed": games, "plies_per_game": plies_per_game,
@@ -476,6 +489,9 @@ def main():
                          "note": "achieved counts the ALGORITHMIC flops of the leaf CNN (flop_per_leaf_eval, 12.09 MFLOP at 8x8); "
                                  "the f16x3 path issues ~2.9x that many MFMA flops",
                          "launches": launches, "avg_launch_ms": kernel_ms / launches if launches else None,
+                         "kernel_launches_per_search": eng.search_parts(),
+                         "launch_note": "`launches` counts searches (one per move step); a search is kernel_launches_per_search "
+                                        "launches of the kernel back to back, timed together by one pair of HIP events",
                          "flop_per_leaf_eval": flop, "leaf_evals_per_launch": evals_per_gpu / launches if launches else None},
         }
         # the tree / board side of the same launch against the HBM roof: algorithmic bytes per
@@ -489,7 +505,7 @@ def main():
         # The same workload with a TRAINED net: sharp priors make deep, narrow trees, the regime in which
         # the descent (not the leaf CNN) bounds a launch.  Own pre-roll, own timed region, one GPU only.
         model = args.model or os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden", "g10_trained.npz")
-        if world == 1 and model != "none" and os.path.exists(model):
+        if world == 1 and model != "none" and not args.weights and os.path.exists(model):
             tparams = trained_params(model, n, dev)
             if tparams is not None:
                 eng.set_weights(tparams)

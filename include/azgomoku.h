@@ -272,10 +272,14 @@ int azg_train_step(azg_handle *h, int n, const float *states, const float *mcts_
                    float *adam_v, int64_t step, double lr, double beta1, double beta2, double eps,
                    double weight_decay, float *loss, float *entropy);
 
-/* Timing of the search kernel, measured with HIP events on the handle's stream:
- * number of launches since the last call, summed milliseconds, and summed leaf
- * evaluations (playouts that reached the CNN).  Resets the counters. */
+/* Timing of the search of a move (MCTS.get_move_probs, mcts_alphaZero.py:154-181), measured with HIP
+ * events on the handle's stream: number of searches since the last call, summed milliseconds, and
+ * summed leaf evaluations (playouts that reached the CNN).  Resets the counters.
+ * A search is azg_search_parts() kernel launches back to back, each with its share of the move's
+ * playouts (the trees do not depend on the number; AZG_SEARCH_PARTS in the environment of azg_create
+ * sets it, default 4 for net-driven boards up to 8x8, 2 for larger ones, 1 for the synthetic priors). */
 int azg_profile(azg_handle *h, int64_t *launches, double *ms, int64_t *playouts);
+int azg_search_parts(azg_handle *h);
 
 /* The reference's tree is unbounded under tree reuse (mcts_alphaZero.py:183-192 keeps the whole
  * subtree of the move played).  A game whose tree may outgrow its arena during the next search is

@@ -9,7 +9,9 @@ for round in 1 2; do
     python - "$v" "$round" gpurun_out/ab_$tag/${v}_$round.json <<'P'
 import json,sys
 d=json.load(open(sys.argv[3]))
-print("%-14s r%s launch %.3f ms  step %.3f ms  (step-launch %.3f)  frac %.4f  playouts/s %.3e games/s %.0f" % (sys.argv[1], sys.argv[2], d["roofline"]["avg_launch_ms"], d["ms_per_step"], d["ms_per_step"]-d["roofline"]["avg_launch_ms"], d["roofline"]["frac"], d["playouts_per_s"], d["value"]))
+t = d.get("trained_net") or {}
+print("%-14s r%s launch %.3f ms  step %.3f ms  (step-launch %.3f)  frac %.4f  playouts/s %.3e games/s %.0f%s" % (sys.argv[1], sys.argv[2], d["roofline"]["avg_launch_ms"], d["ms_per_step"], d["ms_per_step"]-d["roofline"]["avg_launch_ms"], d["roofline"]["frac"], d["playouts_per_s"], d["value"],
+      "   trained net: launch %.3f ms  step %.3f ms  %.1f plies/game" % (t["avg_launch_ms"], t["ms_per_step"], t["plies_per_game"]) if t else ""))
 P
   done
 done

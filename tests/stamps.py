@@ -19,7 +19,10 @@ print("exactness of this build: root priors differ from the evaluation kernel in
          "EXACT" if _ex["root_priors_differ_from_eval_kernel"] == 0 and _ex["trees_differ_from_the_most_common"] == 0
          and _ex["eval_kernel_max_abs_err_vs_oracle_net"] < 1e-5 else "NOT EXACT: the figures below are of searches that differ from the shipped ones"))
 eng = az.SelfPlayEngine(n, 5, int(os.environ.get("PLAYOUTS", 400 if n == 8 else 200)), B, cnn_mode=int(os.environ.get("CNN_MODE", "0")))
-if os.environ.get("MODEL"):              # a trained net instead of random weights: deep, narrow trees
+if os.environ.get("MODEL", "").endswith(".npz"):     # the reference's trained nets as the fixture holds them (Theano layout)
+    with np.load(os.environ["MODEL"]) as _d:
+        eng.set_weights([_d["params_%d_%d" % (n, i)] for i in range(16)], layout=az._lib.LAYOUT_THEANO)
+elif os.environ.get("MODEL"):              # a trained net instead of random weights: deep, narrow trees
     from alphazero_gomoku_amd.net import PolicyValueNet
     PolicyValueNet(n, n, model_file=os.environ["MODEL"]).sync_engine(eng, -1)
 else:
@@ -45,7 +48,7 @@ per_group = 4 if n <= 8 else (2 if os.environ.get("DUAL") else 1)             # 
 raw = list(out)
 out = [v / ngroups for v in out]
 depth_sum = out[18]; out[18] = 0.0                     # slot 18 counts path entries (root .. leaf) of wave 0's descents
-tot = sum(out[:20])
+tot = sum(out[:28])
 print("launches", l, "ms/launch", ms / l, "cycles/playout", tot / (4 * eng.n_playout),
       "clock GHz", out[30] / max(1, out[31]) * 0.1, "path entries per descent (root .. leaf)", depth_sum / (4 * eng.n_playout))
 if os.environ.get("DUAL"):
@@ -65,6 +68,14 @@ if os.environ.get("DUAL"):
     names = []
 for i, nm in enumerate(names):
     print("%-14s %8.0f cyc/playout  %5.1f%%" % (nm, out[i] / (4 * eng.n_playout), 100.0 * out[i] / tot))
+if not os.environ.get("DUAL") and sum(out[20:24]) > 0:
+    # inside the descent (wave 0's, per level below the root): slots 20-23 of wave_select
+    levels = depth_sum - 4 * eng.n_playout
+    print("inside the descent: %.2f levels per descent; cycles per level:" % (levels / (4 * eng.n_playout)))
+    for i, nm in zip(range(20, 24), ("path record of the level above + loop head", "loads issued -> float32 screen evaluated",
+                                      "double-precision pass (near-ties only) + argmax", "hand-over of the chosen child (readlanes)")):
+        print("  %-52s %7.0f   (%6.0f per playout)" % (nm, out[i] / levels, out[i] / (4 * eng.n_playout)))
+    print("  %-52s           (%6.0f per playout)" % ("rest of select + end test (slot 0)", out[0] / (4 * eng.n_playout)))
 wg = np.array(raw[32:32 + 2 * ngroups], dtype=np.int64).reshape(-1, 2)
 ms_wg = wg[:, 0] * 1e-5
 xcc = (wg[:, 1] >> 32) & 0xF

@@ -205,6 +205,33 @@ def test_net_search_bit_exact_vs_oracle_with_gpu_priors(az, oracle, cnn_mode):
         ev.close()
 
 
+@pytest.mark.parametrize("n,k,npo,B", [(8, 5, 101, 6), (15, 5, 37, 3)])
+def test_search_in_several_launches_gives_the_same_trees(az, n, k, npo, B, monkeypatch):
+    """A move's playouts spread over 1, 2, 7 or more launches than playouts (AZG_SEARCH_PARTS, read by
+    azg_create): three plies of B games with tree reuse, and after every search the same visit
+    counts, Q values and priors at the root, bit for bit."""
+    params = helpers.make_params(n, seed=100 + n, scale=2.0)
+    want = None
+    for parts in ("1", "2", "7", "64"):
+        monkeypatch.setenv("AZG_SEARCH_PARTS", parts)
+        eng = az.SelfPlayEngine(n, k, npo, B)
+        assert eng.search_parts() == min(int(parts), npo)
+        eng.set_weights(params)
+        eng.reset_games(seeds=np.arange(B, dtype=np.uint32) + 5)
+        got = []
+        for _ in range(3):
+            eng.search()
+            visits, q, p, rn = eng.root_stats()
+            got.append((visits.copy(), q.copy(), p.copy(), rn.copy()))
+            eng.sample_and_advance(1.0)
+        eng.close()
+        if want is None:
+            want = got
+        for a, b in zip(want, got):
+            for x, y in zip(a, b):
+                assert np.array_equal(x, y), parts
+
+
 @pytest.mark.parametrize("pipelined", [False, True], ids=["host-refill", "device-refill"])
 def test_batched_games_are_independent_of_batching(az, oracle, pipelined):
     """Many games in flight: each slot's game must equal the oracle's game for that seed,
