@@ -35,7 +35,7 @@ REFERENCE_PYTHON_GAMES_PER_S = {(8, 400): 0.0290, (6, 200): 0.1165}
 
 
 def pmc_traffic(cnn, n, playouts, games):
-    """HBM bytes per search launch from the newest committed rocprofv3 --pmc summary of this
+    """HBM bytes per search (all its launches) from the newest committed rocprofv3 --pmc summary of this
     workload (profiles/r*_pmc_search_kernel.json for the default 8x8 workload, ..._c4.json for
     15x15/800/512: FETCH_SIZE and WRITE_SIZE from separate passes, in KiB).  None for any other
     workload or when no summary travels with the tree."""
@@ -49,7 +49,9 @@ def pmc_traffic(cnn, n, playouts, games):
         try:
             with open(f) as fh:
                 d = json.load(fh)
-            return (d["FETCH_SIZE"]["mean_of_last_4"] + d["WRITE_SIZE"]["mean_of_last_4"]) * 1024.0, os.path.basename(f)
+            # (the summary's figures are per kernel launch; a search may be several launches)
+            return ((d["FETCH_SIZE"]["mean_of_last_4"] + d["WRITE_SIZE"]["mean_of_last_4"]) * 1024.0
+                    * d.get("_kernel_launches_per_search", 1)), os.path.basename(f)
         except (OSError, KeyError, ValueError):
             continue
     return None, None

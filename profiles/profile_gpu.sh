@@ -23,6 +23,7 @@ for pass in FETCH_SIZE WRITE_SIZE "SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_VALU_MFMA_BUSY
     timeout -s KILL 400 rocprofv3 --pmc $pass --output-format csv -d "$out/prof_${tag}_pmc_$name" -o run -- python3 bench.py --no-cpu-baseline --model none "$@" --preroll-max 40 --steps 8 --warmup 2 \
         > "$out/${tag}_pmc_$name.json" 2> "$out/${tag}_pmc_$name.err"
 done
-python3 tests/pmc_summary.py "$out/${tag}_pmc_search_kernel.json" "$out/prof_${tag}_pmc_"* > /dev/null
+per_search="$(python3 -c "import json,sys; print(json.load(open(sys.argv[1]))['roofline'].get('kernel_launches_per_search', 1))" "$out/${tag}_bench_under_rocprof.json")"
+python3 tests/pmc_summary.py "$out/${tag}_pmc_search_kernel.json" --launches-per-search "$per_search" "$out/prof_${tag}_pmc_"* > /dev/null
 head -3 "$out/${tag}_kernel_stats.csv"
 cat "$out/${tag}_pmc_search_kernel.json"

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Summarise rocprofv3 --pmc runs of bench.py: per counter, the mean over the last launches of
-the search kernel (steady state).  Usage: python tests/pmc_summary.py OUT.json DIR [DIR ...]
-where every DIR holds a *_counter_collection.csv of one pass."""
+the search kernel (steady state).  Usage: python tests/pmc_summary.py OUT.json [--launches-per-search N] DIR [DIR ...]
+where every DIR holds a *_counter_collection.csv of one pass.  The figures are per KERNEL LAUNCH; a search of
+a move may be several launches (N, recorded as "_kernel_launches_per_search")."""
 import csv
 import glob
 import json
@@ -12,7 +13,10 @@ from collections import defaultdict
 
 def main():
     out_path, dirs = sys.argv[1], sys.argv[2:]
-    res = {}
+    per_search = 1
+    if dirs and dirs[0] == "--launches-per-search":
+        per_search, dirs = int(dirs[1]), dirs[2:]
+    res = {"_kernel_launches_per_search": per_search}
     for d in dirs:
         for path in glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True):
             per = defaultdict(lambda: defaultdict(float))          # counter -> dispatch -> value
