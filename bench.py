@@ -295,6 +295,9 @@ def main():
     ap.add_argument("--weights", default=None,
                     help="run the MAIN measurement with these weights instead of the random-init net (same file forms as "
                          "--model; for profiles of the trained-net regime: `value` is then NOT the headline configuration)")
+    ap.add_argument("--c4-steps", type=int, default=8,
+                    help="timed move steps of the 15x15 / 800 playouts / 512 games measurement reported as `c4` after the "
+                         "headline one (one GPU, default workload only; 0 skips it; adds ~20 s, mostly its pre-roll)")
     ap.add_argument("--trained-steps", type=int, default=48, help="timed move steps of the trained-net measurement")
     args = ap.parse_args()
 
@@ -544,8 +547,47 @@ def main():
                 from oracle import az_oracle
                 out["visit_l1_vs_cpu"] = visit_l1_vs_cpu(az, az_oracle, n, k, args.playouts, params, params_np, drained[-1],
                                                          local_rank, az._lib.CNN_F16X3 if args.cnn == "f16x3" else az._lib.CNN_F32)
+        # BASELINE configuration C4 (15x15 / 5 in a row / 800 playouts / 512 games, random-init net) beside the
+        # headline: the two-wave-group kernel of the larger boards.  Own engine (the headline one is closed
+        # first: its trees hold 20 GB), own pre-roll; few games END in a handful of 46 ms steps, so the
+        # steady-state rate slots / (plies per game x seconds per step) is the figure, as value_from_plies above.
+        default_workload = (n, k, args.playouts, args.games, args.cnn) == (8, 5, 400, 1024, "f16x3") and not args.weights
+        if world == 1 and default_workload and args.c4_steps > 0:
+            eng.close()
+            eng = None
+            n4, k4, po4, b4 = 15, 5, 800, 512
+            eng4 = az.SelfPlayEngine(n4, k4, po4, b4, 5.0, device=local_rank)
+            eng4.set_weights(random_init_params(n4, dev))
+            run4 = SelfPlayRunner(eng4, temp=1.0, seed0=0, first_game_id=0, game_id_stride=1, total=None,
+                                  on_samples=lambda chunk: None, device_samples=True, pipelined=True)
+            run4.start()
+            pre4 = 0
+            while pre4 < 400:
+                run4.step()
+                pre4 += 1
+                if run4.games_delivered >= 2 * b4 and pre4 >= 3.0 * run4.plies_done / run4.games_delivered:
+                    break
+            eng4.profile()
+            torch.cuda.synchronize()
+            g4, t4 = run4.games_done, time.perf_counter()
+            for _ in range(args.c4_steps):
+                run4.step()
+            torch.cuda.synchronize()
+            dt4 = time.perf_counter() - t4
+            run4.finish()
+            l4, k4ms, e4 = eng4.profile()
+            ppg4 = run4.plies_done / run4.games_delivered if run4.games_delivered else None
+            flop4 = FLOP_PER_EVAL[15]
+            out["c4"] = {"workload": "15x15 board 5-in-row, n_playout=800, 512 parallel self-play games, random-init net",
+                         "steps": args.c4_steps, "preroll_steps": pre4, "ms_per_step": dt4 / args.c4_steps * 1e3,
+                         "avg_search_ms": k4ms / l4 if l4 else None, "kernel_launches_per_search": eng4.search_parts(),
+                         "games_completed": run4.games_done - g4, "plies_per_game": ppg4,
+                         "value_from_plies": b4 / (ppg4 * dt4 / args.c4_steps) if ppg4 else None, "unit": "games/s",
+                         "roofline_frac": (flop4 * e4 / (k4ms * 1e-3) / 1e12 / PEAK_TFLOPS["f16x3"]) if k4ms > 0 else None}
+            eng4.close()
         print(json.dumps(out))
-    eng.close()
+    if eng is not None:
+        eng.close()
     if use_dist:
         dist.destroy_process_group()
 

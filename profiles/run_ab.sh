@@ -5,7 +5,7 @@ tag="$1"; shift; bargs="$1"; shift
 mkdir -p gpurun_out/ab_$tag
 for round in 1 2; do
   for v in "$@"; do
-    AZG_LIBRARY=$PWD/abx/libazg_$v.so timeout -k 10 150 python bench.py $bargs --no-cpu-baseline > gpurun_out/ab_$tag/${v}_$round.json 2> gpurun_out/ab_$tag/${v}_$round.err || { echo "FAILED $v round $round"; tail -5 gpurun_out/ab_$tag/${v}_$round.err; exit 1; }
+    AZG_LIBRARY=$PWD/abx/libazg_$v.so timeout -k 10 150 python bench.py $bargs --no-cpu-baseline --c4-steps 0 > gpurun_out/ab_$tag/${v}_$round.json 2> gpurun_out/ab_$tag/${v}_$round.err || { echo "FAILED $v round $round"; tail -5 gpurun_out/ab_$tag/${v}_$round.err; exit 1; }
     python - "$v" "$round" gpurun_out/ab_$tag/${v}_$round.json <<'P'
 import json,sys
 d=json.load(open(sys.argv[3]))
