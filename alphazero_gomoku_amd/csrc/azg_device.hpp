@@ -163,6 +163,12 @@ __device__ inline int azg_tid() { return (int)threadIdx.x; }
 __device__ inline void azg_block_barrier() { __syncthreads(); }
 #endif
 
+#ifndef AZG_GATE_SLEEP
+#define AZG_GATE_SLEEP 16     // s_sleep argument between two polls of a taken gate (x 64 cycles)
+#endif
+#ifndef AZG_GATE_RELEASE
+#define AZG_GATE_RELEASE 0    // how the gate word is given back: 0 agent-scope store, 1 atomic exchange, 2 workgroup-scope store
+#endif
 #ifndef AZG_GATE_TIMED
 #define AZG_GATE_TIMED 0      // 1: a waiting workgroup sleeps until the holder is due to release (see acquire)
 #endif
@@ -206,9 +212,9 @@ struct MatrixGate {
             if (tries < 64) __builtin_amdgcn_s_sleep(1); else __builtin_amdgcn_s_sleep(16);
         }
 #else
-        for (int tries = 0; tries < (AZG_QUAD8 ? 200000 : 2000); tries++) {
+        for (int tries = 0; tries < (AZG_QUAD8 ? 200000 : 2000 * 16 / AZG_GATE_SLEEP); tries++) {
             if (atomicCAS(word, 0, 1) == 0) return;
-            if (AZG_QUAD8) __builtin_amdgcn_s_sleep(1); else __builtin_amdgcn_s_sleep(16);
+            if (AZG_QUAD8) __builtin_amdgcn_s_sleep(1); else __builtin_amdgcn_s_sleep(AZG_GATE_SLEEP);
         }
 #endif
         atomicAdd(&g_gate_giveups[0], 1u);         // the convolutions run beside the partner's this once
@@ -221,7 +227,13 @@ struct MatrixGate {
         const int held = (int)__builtin_amdgcn_s_memtime() - t_acq;
         if (held > 0 && held < (1 << 20)) span = held;
 #endif
+#if AZG_GATE_RELEASE == 1
+        (void)__hip_atomic_exchange(word, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // at the L2, like the polls
+#elif AZG_GATE_RELEASE == 2
+        __hip_atomic_store(word, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#else
         __hip_atomic_store(word, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
     }
 };
 

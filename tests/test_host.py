@@ -490,3 +490,23 @@ def test_bench_with_more_gpus_than_the_machine_has_fails_loudly():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
                         "--launch-timeout", "240"], capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and r.stdout.strip() == "" and "needs GPU" in r.stderr
+
+
+def test_bench_reads_the_trained_fixture_net_in_the_reference_layout():
+    """bench.py --model / --weights: the .npz fixture holds the reference's bundled nets as its model files
+    store them (policy_value_net_numpy.py:103-113: kernels rotated by 180 degrees, matrices as (in, out));
+    the bench hands the engine PyTorch-layout tensors."""
+    import sys
+    import torch
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g10_trained.npz")
+    got = bench.trained_params(path, 8, torch.device("cpu"))
+    assert bench.trained_params(path, 7, torch.device("cpu")) is None
+    with np.load(path) as d:
+        raw = [d["params_8_%d" % i] for i in range(16)]
+    assert len(got) == 16
+    assert tuple(got[8].shape) == (64, 256) and raw[8].shape == (256, 64)          # act_fc1: (out, in) from (in, out)
+    assert np.array_equal(got[8].numpy(), raw[8].T)
+    assert np.array_equal(got[0].numpy(), raw[0][:, :, ::-1, ::-1])
+    assert np.array_equal(got[1].numpy(), raw[1])
