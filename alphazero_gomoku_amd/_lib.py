@@ -18,7 +18,7 @@ ERROR_NAMES = {-1: "AZG_EINVAL", -2: "AZG_EHIP", -3: "AZG_ENOWEIGHTS", -4: "AZG_
 SYMBOLS = ["azg_create", "azg_destroy", "azg_last_error", "azg_set_weights", "azg_reset_games",
            "azg_set_position", "azg_search", "azg_root_stats", "azg_sample_and_advance",
            "azg_advance", "azg_update_with_move", "azg_status", "azg_states",
-           "azg_drain_samples", "azg_eval_batch", "azg_board_step_batch", "azg_profile", "azg_search_parts",
+           "azg_drain_samples", "azg_eval_batch", "azg_board_step_batch", "azg_profile", "azg_search_parts", "azg_set_search_parts",
            "azg_stream", "azg_selfplay_begin", "azg_selfplay_step", "azg_selfplay_fetch",
            "azg_selfplay_end", "azg_equi_data", "azg_pure_search", "azg_host_timing", "azg_arena_stats", "azg_reroot_stats", "azg_selfplay_fetch_packed", "azg_unpack_states", "azg_playout_begin", "azg_playout_end",
            "azg_board_step_batch_static", "azg_gate_stats", "azg_gate_poke",
@@ -121,6 +121,7 @@ def load():
     L.azg_pure_search.argtypes = [vp, C.c_int, C.POINTER(C.c_uint32), i32p]
     L.azg_profile.argtypes = [vp, i64p, f64p, i64p]
     L.azg_search_parts.argtypes = [vp]
+    L.azg_set_search_parts.argtypes = [vp, C.c_int]
     L.azg_stream.argtypes = [vp]
     L.azg_stream.restype = vp
     for name in SYMBOLS:

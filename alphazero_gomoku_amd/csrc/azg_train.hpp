@@ -628,41 +628,51 @@ struct GradSegs {
 };
 enum { GS_CONV_W = 0, GS_PLAIN = 1, GS_HEAD_W = 2, GS_HEAD_B = 3, GS_FC_W = 4, GS_G2 = 5 };
 
-__global__ void grad_assemble_kernel(GradSegs g, int S, float *flat)
+// (64 entries per workgroup, four threads per entry: each sums a quarter of the splits, the quarters are
+//  added in ascending order -- four times the loads in flight of one thread per entry, same bits every time)
+constexpr int kAssembleEntries = 64;
+__global__ __launch_bounds__(256) void grad_assemble_kernel(GradSegs g, int S, float *flat)
 {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= g.total) return;
-    int si = 0;
-#pragma unroll
-    for (int i = 1; i < 16; i++) si += (i < g.n && idx >= g.s[i].start);
-    const GradSeg sg = g.s[si];
-    const int r = idx - sg.start;
-    const ParamLayout L = param_layout(S);
+    __shared__ float quarter[4][kAssembleEntries];
+    const int e = threadIdx.x & (kAssembleEntries - 1), zg = threadIdx.x / kAssembleEntries;
+    const int idx = blockIdx.x * kAssembleEntries + e;
     int dst = -1;
-    if (sg.kind == GS_CONV_W) {                    // [(tap, ci)][co] -> [co][ci][tap];  a = tensor, b = cin
-        const int cout = sg.size / (9 * sg.b), i = r / cout, co = r - i * cout, tap = i / sg.b, ci = i - tap * sg.b;
-        dst = L.off[sg.a] + (co * sg.b + ci) * 9 + tap;
-    } else if (sg.kind == GS_PLAIN) {              // a = tensor
-        dst = L.off[sg.a] + r;
-    } else if (sg.kind == GS_HEAD_W) {             // [ch][8] -> act_conv1 [c][128] (c < 4), val_conv1 [c - 4][128]
-        const int ch = r >> 3, c = r & 7;
-        if (c < 4) dst = L.off[6] + c * 128 + ch;
-        else if (c < 6) dst = L.off[10] + (c - 4) * 128 + ch;
-    } else if (sg.kind == GS_HEAD_B) {
-        if (r < 4) dst = L.off[7] + r;
-        else if (r < 6) dst = L.off[11] + r - 4;
-    } else if (sg.kind == GS_FC_W) {               // [k][out] -> [out][k];  a = tensor, b = outputs
-        const int k = r / sg.b, o = r - k * sg.b, K = sg.size / sg.b;
-        dst = L.off[sg.a] + o * K + k;
-    } else {                                       // val_fc2: columns 0-63 weight, 64 bias
-        if (r < 64) dst = L.off[14] + r;
-        else if (r == 64) dst = L.off[15];
-    }
-    if (dst < 0) return;
     float s = 0.f;
+    if (idx < g.total) {
+        int si = 0;
+#pragma unroll
+        for (int i = 1; i < 16; i++) si += (i < g.n && idx >= g.s[i].start);
+        const GradSeg sg = g.s[si];
+        const int r = idx - sg.start;
+        const ParamLayout L = param_layout(S);
+        if (sg.kind == GS_CONV_W) {                    // [(tap, ci)][co] -> [co][ci][tap];  a = tensor, b = cin
+            const int cout = sg.size / (9 * sg.b), i = r / cout, co = r - i * cout, tap = i / sg.b, ci = i - tap * sg.b;
+            dst = L.off[sg.a] + (co * sg.b + ci) * 9 + tap;
+        } else if (sg.kind == GS_PLAIN) {              // a = tensor
+            dst = L.off[sg.a] + r;
+        } else if (sg.kind == GS_HEAD_W) {             // [ch][8] -> act_conv1 [c][128] (c < 4), val_conv1 [c - 4][128]
+            const int ch = r >> 3, c = r & 7;
+            if (c < 4) dst = L.off[6] + c * 128 + ch;
+            else if (c < 6) dst = L.off[10] + (c - 4) * 128 + ch;
+        } else if (sg.kind == GS_HEAD_B) {
+            if (r < 4) dst = L.off[7] + r;
+            else if (r < 6) dst = L.off[11] + r - 4;
+        } else if (sg.kind == GS_FC_W) {               // [k][out] -> [out][k];  a = tensor, b = outputs
+            const int k = r / sg.b, o = r - k * sg.b, K = sg.size / sg.b;
+            dst = L.off[sg.a] + o * K + k;
+        } else {                                       // val_fc2: columns 0-63 weight, 64 bias
+            if (r < 64) dst = L.off[14] + r;
+            else if (r == 64) dst = L.off[15];
+        }
+        if (dst >= 0) {
+            const int per = (sg.splits + 3) / 4, z0 = zg * per, z1 = min(sg.splits, z0 + per);
 #pragma unroll 8
-    for (int z = 0; z < sg.splits; z++) s += sg.part[(size_t)z * sg.size + r];
-    flat[dst] = s;
+            for (int z = z0; z < z1; z++) s += sg.part[(size_t)z * sg.size + r];
+        }
+    }
+    quarter[zg][e] = s;
+    __syncthreads();
+    if (zg == 0 && dst >= 0) flat[dst] = ((quarter[0][e] + quarter[1][e]) + quarter[2][e]) + quarter[3][e];
 }
 
 // loss = mean value loss + mean policy loss, entropy = mean entropy (policy_value_net_pytorch.py:128-147)

@@ -953,11 +953,19 @@ extern "C" int azg_set_position(azg_handle *h, int slot, const uint64_t stones1[
 static int search_parts_of(const azg_handle *h)
 {
     int want = h->search_parts;
-    if (want <= 0) want = h->cfg.prior_mode != AZG_PRIOR_NET ? 1 : (h->cfg.board_n <= 8 ? 4 : 2);
+    if (want <= 0) want = h->cfg.prior_mode != AZG_PRIOR_NET ? 1 : (h->cfg.board_n <= 8 ? 8 : 2);
     return std::max(1, std::min(want, h->st.n_playout));
 }
 
 extern "C" int azg_search_parts(azg_handle *h) { return h ? search_parts_of(h) : AZG_EINVAL; }
+
+extern "C" int azg_set_search_parts(azg_handle *h, int parts)
+{
+    if (!h) return AZG_EINVAL;
+    if (parts < 0 || parts > 64) return fail(h, AZG_EINVAL, "search parts must be 0 (default) ... 64");
+    h->search_parts = parts;
+    return AZG_OK;
+}
 
 extern "C" int azg_search(azg_handle *h)
 {
@@ -981,7 +989,10 @@ extern "C" int azg_search(azg_handle *h)
     // (all parity tests run with 1 and with 4 parts).  Measured, same box, interleaved rounds, 8x8 /
     // 400 / 1024: 4 parts instead of 1: 11.40 -> 11.06 ms per move on one box, 10.98 -> 10.99 on another
     // (the single launch varies between boxes, the split one does not); with a trained net 11.50 -> 11.05
-    // and 11.30 -> 10.72; 8 parts 11.07 / 10.89, 16 parts 11.13 / 11.0.  Dealing the games to other XCDs
+    // and 11.30 -> 10.72; 8 parts 11.07 / 10.89, 16 parts 11.13 / 11.0.  Kernels of other streams slip in
+    // between two parts (beside a search launch they find no room on any CU): a learning run with one
+    // policy update per move step plays 2 731 / 2 788 / 2 906 games/s including training with 4 / 8 / 16
+    // parts.  So 8 by default, and the training loop asks for 16.  Dealing the games to other XCDs
     // in every part changed nothing on top (every launch still ends with its slowest XCD).  15x15 / 800 /
     // 512 (two-wave-group kernel): the search itself 43.6 -> 43.7 (2 parts) -> 44.0 ms (4), but the copy
     // kernels of the noise upload, which find no room beside that kernel, slip in between two parts:
@@ -1882,7 +1893,7 @@ static int train_backward_enqueue(azg_handle *h, int n, const float *states, con
     seg(w.vpart, 2 * S * 64, w.fsplits, GS_FC_W, 12, 64);
     seg(w.vbpart, 64, w.fsplits, GS_PLAIN, 13, 0);
     seg(w.g2part, 128, w.gsplits, GS_G2, 0, 0);
-    hipLaunchKernelGGL(grad_assemble_kernel, dim3((gs.total + 255) / 256), dim3(256), 0, s, gs, S, grads);
+    hipLaunchKernelGGL(grad_assemble_kernel, dim3((gs.total + kAssembleEntries - 1) / kAssembleEntries), dim3(256), 0, s, gs, S, grads);
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipMemcpyAsync(w.h_loss, w.lossout, 8, hipMemcpyDeviceToHost, s));
     return AZG_OK;

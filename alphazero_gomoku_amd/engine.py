@@ -295,6 +295,10 @@ class SelfPlayEngine:
         """Kernel launches a move's playouts are spread over (azg_search_parts)."""
         return int(self.L.azg_search_parts(self.h))
 
+    def set_search_parts(self, parts):
+        """Spread a move's playouts over `parts` launches (0: the library's default); same trees."""
+        self._chk(self.L.azg_set_search_parts(self.h, int(parts)))
+
     def profile(self):
         """(search launches, summed ms on the engine's stream, summed leaf evaluations) since last call."""
         a, b, c = C.c_int64(0), C.c_double(0.0), C.c_int64(0)

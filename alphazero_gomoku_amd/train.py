@@ -107,6 +107,11 @@ class TrainPipeline:
             pass
         per_rank = (max(1, play_batch_size) + self.world - 1) // self.world
         self.engine = SelfPlayEngine(board_width, n_in_row, n_playout, min(n_parallel, per_rank), c_puct, device=device)
+        if continuous and "AZG_SEARCH_PARTS" not in os.environ and board_width <= 8:
+            # policy updates run between move steps, beside the search in flight: their kernels reach the
+            # GPU between two launches of a search, so more, shorter launches (same trees) let them through
+            # sooner: 2 731 / 2 788 / 2 906 games/s including training with 4 / 8 / 16 launches per move
+            self.engine.set_search_parts(16)
         self._engine_version = -1
         self.episode_len = 0
         self.policy_updates = 0

@@ -277,9 +277,12 @@ int azg_train_step(azg_handle *h, int n, const float *states, const float *mcts_
  * summed leaf evaluations (playouts that reached the CNN).  Resets the counters.
  * A search is azg_search_parts() kernel launches back to back, each with its share of the move's
  * playouts (the trees do not depend on the number; AZG_SEARCH_PARTS in the environment of azg_create
- * sets it, default 4 for net-driven boards up to 8x8, 2 for larger ones, 1 for the synthetic priors). */
+ * sets it, azg_set_search_parts overrides it (0 = the default again): default 8 for net-driven boards up
+ * to 8x8, 2 for larger ones, 1 for the synthetic priors.  Kernels of other streams -- a training
+ * step -- get onto the GPU between two parts, not beside a resident one.) */
 int azg_profile(azg_handle *h, int64_t *launches, double *ms, int64_t *playouts);
 int azg_search_parts(azg_handle *h);
+int azg_set_search_parts(azg_handle *h, int parts);
 
 /* The reference's tree is unbounded under tree reuse (mcts_alphaZero.py:183-192 keeps the whole
  * subtree of the move played).  A game whose tree may outgrow its arena during the next search is

@@ -216,6 +216,9 @@ def test_search_in_several_launches_gives_the_same_trees(az, n, k, npo, B, monke
         monkeypatch.setenv("AZG_SEARCH_PARTS", parts)
         eng = az.SelfPlayEngine(n, k, npo, B)
         assert eng.search_parts() == min(int(parts), npo)
+        if parts == "2":
+            eng.set_search_parts(5)                          # at run time as well
+            assert eng.search_parts() == 5
         eng.set_weights(params)
         eng.reset_games(seeds=np.arange(B, dtype=np.uint32) + 5)
         got = []
