@@ -495,8 +495,10 @@ def main():
                                  "the f16x3 path issues ~2.9x that many MFMA flops",
                          "launches": launches, "avg_launch_ms": kernel_ms / launches if launches else None,
                          "kernel_launches_per_search": eng.search_parts(),
+                         "avg_kernel_launch_ms": (kernel_ms / launches / eng.search_parts()) if launches else None,
                          "launch_note": "`launches` counts searches (one per move step); a search is kernel_launches_per_search "
-                                        "launches of the kernel back to back, timed together by one pair of HIP events",
+                                        "launches of the kernel back to back, timed together by one pair of HIP events; "
+                                        "avg_kernel_launch_ms is what rocprofv3's kernel statistics show per call",
                          "flop_per_leaf_eval": flop, "leaf_evals_per_launch": evals_per_gpu / launches if launches else None},
         }
         # the tree / board side of the same launch against the HBM roof: algorithmic bytes per
