@@ -1,11 +1,11 @@
 #!/bin/bash
 # usage (through gpurun): profiles/parts_ab.sh "bench args" p1 p2 ...  -- bench.py with a move's playouts spread over
-# p launches (AZG_SEARCH_PARTS; a p written as 4x: without dealing the games to other XCDs), two interleaved rounds
+# p launches (AZG_SEARCH_PARTS), two interleaved rounds
 bargs="$1"; shift
 mkdir -p gpurun_out/ab_parts
 for round in 1 2; do
   for v in "$@"; do
-    AZG_SEARCH_PARTS=${v%x} AZG_SEARCH_XOR=$([ "${v%x}" = "$v" ] && echo 1 || echo 0) timeout -k 10 200 python bench.py $bargs --no-cpu-baseline --c4-steps 0 > gpurun_out/ab_parts/${v}_$round.json 2> gpurun_out/ab_parts/${v}_$round.err || { echo "FAILED $v round $round"; tail -5 gpurun_out/ab_parts/${v}_$round.err; exit 1; }
+    AZG_SEARCH_PARTS=$v timeout -k 10 200 python bench.py $bargs --no-cpu-baseline --c4-steps 0 > gpurun_out/ab_parts/${v}_$round.json 2> gpurun_out/ab_parts/${v}_$round.err || { echo "FAILED $v round $round"; tail -5 gpurun_out/ab_parts/${v}_$round.err; exit 1; }
     python - "$v" "$round" gpurun_out/ab_parts/${v}_$round.json <<'P'
 import json,sys
 d=json.load(open(sys.argv[3]))
