@@ -1677,6 +1677,10 @@ static int train_prepare(azg_handle *h, int n)
 {
     auto &w = h->tw;
     const int S = h->st.S;
+    // (the GEMM kernels address their operands with 32-bit byte offsets: the widest activation array,
+    //  batch * cells * 128 channels of float32, has to stay below 2 GiB)
+    if ((long long)n * S * 128 * 4 >= (1LL << 31))
+        return fail(h, AZG_EINVAL, "a training batch of %d positions is too large (at most %lld on this board)", n, (1LL << 31) / (512LL * S) - 1);
     if (!w.stream) HIPCHK(h, hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking));
     if (!w.h_loss) HIPCHK(h, hipHostMalloc((void **)&w.h_loss, 32));   // loss, entropy; a double at +8: KL
     const int M = n * S;

@@ -530,3 +530,15 @@ def test_native_data_parallel_step_two_ranks_on_one_gpu(az):
     for a, b, w in zip(res[0][2], res[1][2], want):
         assert np.array_equal(a, b)
         np.testing.assert_allclose(a, w, rtol=0, atol=3e-6)
+
+
+def test_training_batch_beyond_the_32_bit_offsets_is_refused(az):
+    """The training GEMMs address activations with 32-bit byte offsets: a batch whose widest activation
+    array (batch x cells x 128 floats) would reach 2 GiB is refused with a clear error, nothing is launched."""
+    import torch
+    net = az.PolicyValueNet(8, 8)
+    too_many = (1 << 31) // (512 * 64)
+    with pytest.raises(Exception, match="too large"):
+        net.policy_value_in_training(torch.zeros((too_many, 4, 8, 8), device=net.device))
+    probs, vals = net.policy_value_in_training(torch.zeros((3, 4, 8, 8), device=net.device))     # the handle still works
+    assert probs.shape == (3, 64) and bool(torch.isfinite(probs).all())
