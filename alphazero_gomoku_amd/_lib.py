@@ -22,7 +22,7 @@ SYMBOLS = ["azg_create", "azg_destroy", "azg_last_error", "azg_set_weights", "az
            "azg_stream", "azg_selfplay_begin", "azg_selfplay_step", "azg_selfplay_fetch",
            "azg_selfplay_end", "azg_equi_data", "azg_pure_search", "azg_host_timing", "azg_arena_stats", "azg_reroot_stats", "azg_selfplay_fetch_packed", "azg_unpack_states", "azg_playout_begin", "azg_playout_end",
            "azg_board_step_batch_static", "azg_gate_stats", "azg_gate_poke",
-           "azg_train_param_count", "azg_train_forward", "azg_train_backward", "azg_train_adam", "azg_train_step"]
+           "azg_train_param_count", "azg_train_forward", "azg_train_backward", "azg_train_adam", "azg_train_step", "azg_train_epoch"]
 
 
 class AzgError(RuntimeError):
@@ -118,6 +118,8 @@ def load():
     L.azg_train_adam.argtypes = [vp, C.POINTER(vp), vp, vp, vp, C.c_int64, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double]
     L.azg_train_step.argtypes = [vp, C.c_int, vp, vp, vp, C.POINTER(vp), vp, vp, vp, C.c_int64, C.c_double, C.c_double,
                                  C.c_double, C.c_double, C.c_double, f32p, f32p]
+    L.azg_train_epoch.argtypes = [vp, C.c_int, vp, vp, vp, C.POINTER(vp), vp, vp, vp, C.c_int64, C.c_double, C.c_double,
+                                  C.c_double, C.c_double, C.c_double, f32p, f32p, C.c_int, vp, vp, vp, vp, C.POINTER(C.c_double)]
     L.azg_pure_search.argtypes = [vp, C.c_int, C.POINTER(C.c_uint32), i32p]
     L.azg_profile.argtypes = [vp, i64p, f64p, i64p]
     L.azg_search_parts.argtypes = [vp]

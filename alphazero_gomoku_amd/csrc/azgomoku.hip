@@ -1795,6 +1795,27 @@ static FcArgs train_fc_args(azg_handle *h, int n, const TrainParams &P)
     return f;
 }
 
+// the forward pass of n positions (and the KL test's number against old_probs, left in h_loss) on the
+// training stream, no synchronisation
+static int train_forward_enqueue(azg_handle *h, int n, const float *states, const TrainParams &P, float *probs, float *values,
+                                 const float *old_probs)
+{
+    auto &w = h->tw;
+    const int M = n * h->st.S;
+    hipLaunchKernelGGL(planes_to_rows_kernel, dim3((M + 255) / 256), dim3(256), 0, w.stream, states, n, h->st.S, w.x4);
+    train_forward_convs(h, n, P);
+    FcArgs f = train_fc_args(h, n, P);
+    f.probs = probs; f.values = values; f.oldp = old_probs; f.klparts = w.klparts;
+    hipLaunchKernelGGL(fc_sample_kernel, dim3(n), dim3(256), 0, w.stream, f);
+    if (old_probs) {
+        double *kl_dev = reinterpret_cast<double *>(w.lossout + 4), *kl_host = reinterpret_cast<double *>(w.h_loss + 2);
+        hipLaunchKernelGGL(kl_kernel, dim3(1), dim3(256), 0, w.stream, (const double *)w.klparts, n, kl_dev);
+        HIPCHK(h, hipMemcpyAsync(kl_host, kl_dev, 8, hipMemcpyDeviceToHost, w.stream));
+    }
+    HIPCHK(h, hipGetLastError());
+    return AZG_OK;
+}
+
 extern "C" int azg_train_forward(azg_handle *h, int n, const float *states, const float *const params[16], float *probs,
                                  float *values, const float *old_probs, double *kl)
 {
@@ -1807,23 +1828,11 @@ extern "C" int azg_train_forward(azg_handle *h, int n, const float *states, cons
     if (rc) return rc;
     if (!is_device_ptr(states) || !is_device_ptr(probs)) return fail(h, AZG_EINVAL, "azg_train_forward takes device pointers");
     if ((rc = train_prepare(h, n))) return rc;
-    auto &w = h->tw;
     TrainParams P;
     for (int i = 0; i < 16; i++) P.p[i] = const_cast<float *>(params[i]);
-    const int M = n * h->st.S;
-    hipLaunchKernelGGL(planes_to_rows_kernel, dim3((M + 255) / 256), dim3(256), 0, w.stream, states, n, h->st.S, w.x4);
-    train_forward_convs(h, n, P);
-    FcArgs f = train_fc_args(h, n, P);
-    f.probs = probs; f.values = values; f.oldp = old_probs; f.klparts = w.klparts;
-    hipLaunchKernelGGL(fc_sample_kernel, dim3(n), dim3(256), 0, w.stream, f);
-    double *kl_dev = reinterpret_cast<double *>(w.lossout + 4), *kl_host = reinterpret_cast<double *>(w.h_loss + 2);
-    if (old_probs) {
-        hipLaunchKernelGGL(kl_kernel, dim3(1), dim3(256), 0, w.stream, (const double *)w.klparts, n, kl_dev);
-        HIPCHK(h, hipMemcpyAsync(kl_host, kl_dev, 8, hipMemcpyDeviceToHost, w.stream));
-    }
-    HIPCHK(h, hipGetLastError());
-    HIPCHK(h, hipStreamSynchronize(w.stream));
-    if (old_probs) *kl = *kl_host;
+    if ((rc = train_forward_enqueue(h, n, states, P, probs, values, old_probs))) return rc;
+    HIPCHK(h, hipStreamSynchronize(h->tw.stream));
+    if (old_probs) *kl = *reinterpret_cast<double *>(h->tw.h_loss + 2);
     return AZG_OK;
 }
 
@@ -1970,6 +1979,36 @@ extern "C" int azg_train_step(azg_handle *h, int n, const float *states, const f
     HIPCHK(h, hipStreamSynchronize(h->tw.stream));
     if (loss) *loss = h->tw.h_loss[0];
     if (entropy) *entropy = h->tw.h_loss[1];
+    return AZG_OK;
+}
+
+extern "C" int azg_train_epoch(azg_handle *h, int n, const float *states, const float *mcts_probs, const float *winners,
+                               float *const params[16], float *grads, float *adam_m, float *adam_v, int64_t step, double lr,
+                               double beta1, double beta2, double eps, double weight_decay, float *loss, float *entropy,
+                               int n_all, const float *states_all, float *probs, float *values, const float *old_probs, double *kl)
+{
+    if (!h || n < 1 || n_all < 1 || !states || !mcts_probs || !winners || !grads || !adam_m || !adam_v || step < 1 || !states_all || !probs ||
+        !values || !old_probs || !kl)
+        return fail(h, AZG_EINVAL, "bad argument");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    int rc = train_check_ptrs(h, params);
+    if (rc) return rc;
+    if (!is_device_ptr(states) || !is_device_ptr(grads) || !is_device_ptr(adam_m) || !is_device_ptr(states_all) || !is_device_ptr(probs) ||
+        !is_device_ptr(old_probs))
+        return fail(h, AZG_EINVAL, "azg_train_epoch takes device pointers (loss, entropy and kl are host pointers)");
+    // (room for the larger of the two batches; the partial-sum splits of the backward pass are those of ITS
+    //  batch size, so the step is the same, bit for bit, as azg_train_step's)
+    if ((rc = train_prepare(h, std::max(n, n_all)))) return rc;
+    if ((rc = train_prepare(h, n))) return rc;
+    TrainParams P;
+    for (int i = 0; i < 16; i++) P.p[i] = params[i];
+    if ((rc = train_backward_enqueue(h, n, states, mcts_probs, winners, P, grads))) return rc;
+    if ((rc = train_adam_enqueue(h, P, grads, adam_m, adam_v, step, lr, beta1, beta2, eps, weight_decay))) return rc;
+    if ((rc = train_forward_enqueue(h, n_all, states_all, P, probs, values, old_probs))) return rc;
+    HIPCHK(h, hipStreamSynchronize(h->tw.stream));
+    if (loss) *loss = h->tw.h_loss[0];
+    if (entropy) *entropy = h->tw.h_loss[1];
+    *kl = *reinterpret_cast<double *>(h->tw.h_loss + 2);
     return AZG_OK;
 }
 

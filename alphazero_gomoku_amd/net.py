@@ -324,6 +324,40 @@ class PolicyValueNet(object):
         self.version += 1
         return float(loss.value), float(entropy.value)
 
+    def train_epoch(self, state_batch, mcts_probs, winner_batch, lr, kl_states, old_probs):
+        """One epoch of policy_update's loop (train.py:176-201) in one library call and one wait:
+        train_step on the batch, then the KL test's forward pass of kl_states with the updated
+        parameters.  Returns (loss, entropy, new_probs [B,S], new_values [B,1], kl).  CUDA tensors;
+        single process (data-parallel training exchanges gradients between the two halves: train_step +
+        policy_value_in_training)."""
+        dev = self.device
+        if not self.native_train or self.data_parallel:
+            raise RuntimeError("train_epoch is the library's single-process path")
+
+        def tensor(a):
+            return a.to(device=dev, dtype=torch.float32).contiguous()
+        s, p, z = tensor(state_batch), tensor(mcts_probs), tensor(winner_batch).reshape(-1)
+        ks, old = tensor(kl_states), tensor(old_probs)
+        n, n_all, cells = int(s.shape[0]), int(ks.shape[0]), self.board_width * self.board_height
+        eng = self._engine_handle()
+        if self._adam is None:
+            total = int(eng.L.azg_train_param_count(eng.h))
+            self._adam = tuple(torch.zeros(total, dtype=torch.float32, device=dev) for _ in range(3))
+        grad, m, v = self._adam
+        arr, keep = self._param_ptrs()
+        probs = torch.empty((n_all, cells), dtype=torch.float32, device=dev)
+        vals = torch.empty(n_all, dtype=torch.float32, device=dev)
+        loss, entropy, kl = C.c_float(0.0), C.c_float(0.0), C.c_double(0.0)
+        torch.cuda.current_stream(dev).synchronize()           # the batch exists before the library's stream reads it
+        self._adam_step += 1
+        eng._chk(eng.L.azg_train_epoch(eng.h, n, C.c_void_p(s.data_ptr()), C.c_void_p(p.data_ptr()), C.c_void_p(z.data_ptr()), arr,
+                                       C.c_void_p(grad.data_ptr()), C.c_void_p(m.data_ptr()), C.c_void_p(v.data_ptr()),
+                                       self._adam_step, float(lr), 0.9, 0.999, 1e-8, self.l2_const, C.byref(loss), C.byref(entropy),
+                                       n_all, C.c_void_p(ks.data_ptr()), C.c_void_p(probs.data_ptr()), C.c_void_p(vals.data_ptr()),
+                                       C.c_void_p(old.data_ptr()), C.byref(kl)))
+        self.version += 1
+        return float(loss.value), float(entropy.value), probs, vals.reshape(-1, 1), float(kl.value)
+
     def get_policy_param(self):
         return self.policy_value_net.state_dict()
 

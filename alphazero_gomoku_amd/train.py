@@ -225,7 +225,14 @@ class TrainPipeline:
         sl = slice(self.rank, None, self.world)                               # this rank's share of the mini-batch
         kl, loss, entropy = 0.0, float("nan"), float("nan")
         new_v = old_v
+        fused = with_kl and self.world == 1 and getattr(net, "native_train", False) and hasattr(net, "train_epoch")
         for _ in range(self.epochs):
+            if fused:                                                         # step + KL forward: one library call, one wait
+                loss, entropy, new_probs, new_v, kl = net.train_epoch(state_batch, mcts_probs_batch, winner_batch,
+                                                                      self.learn_rate * self.lr_multiplier, state_batch, old_probs)
+                if kl > self.kl_targ * 4:
+                    break
+                continue
             loss, entropy = net.train_step(state_batch[sl], mcts_probs_batch[sl], winner_batch[sl],
                                            self.learn_rate * self.lr_multiplier)
             if with_kl:

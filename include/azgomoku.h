@@ -271,6 +271,15 @@ int azg_train_step(azg_handle *h, int n, const float *states, const float *mcts_
                    const float *winners, float *const params[16], float *grads, float *adam_m,
                    float *adam_v, int64_t step, double lr, double beta1, double beta2, double eps,
                    double weight_decay, float *loss, float *entropy);
+/* One epoch of TrainPipeline.policy_update's loop (train.py:176-201) in one call, one wait: azg_train_step on
+ * the n training positions, then azg_train_forward of the n_all positions of the KL test with the updated
+ * parameters (probs [n_all,S], values [n_all], *kl against old_probs). */
+int azg_train_epoch(azg_handle *h, int n, const float *states, const float *mcts_probs,
+                    const float *winners, float *const params[16], float *grads, float *adam_m,
+                    float *adam_v, int64_t step, double lr, double beta1, double beta2, double eps,
+                    double weight_decay, float *loss, float *entropy, int n_all,
+                    const float *states_all, float *probs, float *values, const float *old_probs,
+                    double *kl);
 
 /* Timing of the search of a move (MCTS.get_move_probs, mcts_alphaZero.py:154-181), measured with HIP
  * events on the handle's stream: number of searches since the last call, summed milliseconds, and

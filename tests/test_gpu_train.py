@@ -542,3 +542,25 @@ def test_training_batch_beyond_the_32_bit_offsets_is_refused(az):
         net.policy_value_in_training(torch.zeros((too_many, 4, 8, 8), device=net.device))
     probs, vals = net.policy_value_in_training(torch.zeros((3, 4, 8, 8), device=net.device))     # the handle still works
     assert probs.shape == (3, 64) and bool(torch.isfinite(probs).all())
+
+
+def test_train_epoch_equals_step_then_forward(az):
+    """azg_train_epoch (one call, one wait) against azg_train_step followed by azg_train_forward with the KL
+    number: the same parameters, loss, entropy, probabilities, values and KL, bit for bit, over three epochs."""
+    import torch
+    rs = np.random.RandomState(12)
+    s = torch.as_tensor((rs.rand(96, 4, 8, 8) < 0.3).astype(np.float32), device="cuda:0")
+    pi = torch.as_tensor(rs.dirichlet(np.full(64, 0.3), size=96).astype(np.float32), device="cuda:0")
+    z = torch.as_tensor(rs.choice([-1.0, 0.0, 1.0], size=96).astype(np.float32), device="cuda:0")
+    nets = [az.PolicyValueNet(8, 8) for _ in range(2)]
+    for net in nets:
+        net.load_numpy_params(helpers.make_params(8, seed=77))
+    old, _ = nets[0].policy_value_in_training(s)
+    for epoch in range(3):
+        loss_a, ent_a, probs_a, vals_a, kl_a = nets[0].train_epoch(s[:64], pi[:64], z[:64], 2e-3, s, old)
+        loss_b, ent_b = nets[1].train_step(s[:64], pi[:64], z[:64], 2e-3)
+        probs_b, vals_b, kl_b = nets[1].policy_value_in_training(s, old)
+        assert (loss_a, ent_a, kl_a) == (loss_b, ent_b, kl_b), epoch
+        assert torch.equal(probs_a, probs_b) and torch.equal(vals_a, vals_b)
+        for a, b in zip(nets[0].param_tensors(), nets[1].param_tensors()):
+            assert torch.equal(a, b)
