@@ -1661,7 +1661,7 @@ extern "C" int azg_equi_data(azg_handle *h, int n, const float *states, const do
 // ---------------------------------------------------------------- training step
 // PolicyValueNet.train_step (policy_value_net_pytorch.py:117-148) and the forward pass of
 // PolicyValueNet.policy_value (:80-94) on a mini-batch, in float32 (kernels: azg_train.hpp).
-static const int kTrainCin[3] = {4, 32, 64}, kTrainCout[3] = {32, 64, 128};
+static constexpr int kTrainCin[3] = {4, 32, 64}, kTrainCout[3] = {32, 64, 128};
 
 // rows per split and number of splits of a reduction over M rows that should give about `want` workgroups
 static void split_rows(int M, int want, int cap, int *rows, int *splits)
@@ -1742,27 +1742,14 @@ static int train_check_ptrs(azg_handle *h, const float *const params[16])
     return AZG_OK;
 }
 
-// Dynamic LDS that a training GEMM asks for on top of its tiles, only to bound how many of its
-// workgroups share a CU (AZG_TRAIN_LDSPAD in the environment, bytes; experiment knob).
-static size_t train_lds_pad()
-{
-    static const size_t pad = [] { const char *e = getenv("AZG_TRAIN_LDSPAD"); return e ? (size_t)atol(e) : (size_t)0; }();
-    return pad;
-}
-template <class K>
-static void train_allow_lds(K kernel)
-{
-    if (train_lds_pad()) (void)hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)train_lds_pad());
-}
-
+// (conv_gemm_kernel's stage arithmetic wants 4 source channels -- CS4 -- or a multiple of the 16 k of a
+//  stage: the channel counts of this net, fixed at compile time)
+static_assert(kTrainCin[0] == 4 && kTrainCin[1] % TKC == 0 && kTrainCin[2] % TKC == 0 && kTrainCout[2] % TKC == 0,
+              "conv_gemm_kernel cannot take these channel counts");
 template <int BN, int MODE, bool CS4 = false>
 static void launch_conv_gemm(hipStream_t s, const ConvGemmArgs &a)
 {
-    static const bool once = (train_allow_lds(conv_gemm_kernel<BN, MODE, CS4>), true);
-    (void)once;
-    // (the kernel's stage arithmetic: 4 source channels, or a multiple of the 16 k of a stage)
-    if (CS4 ? a.Cs != 4 : a.Cs % TKC != 0) { fprintf(stderr, "azgomoku: conv_gemm_kernel cannot take %d source channels\n", a.Cs); abort(); }
-    hipLaunchKernelGGL((conv_gemm_kernel<BN, MODE, CS4>), dim3((a.M + TBM - 1) / TBM, (a.N + BN - 1) / BN), dim3(256), train_lds_pad(), s, a);
+    hipLaunchKernelGGL((conv_gemm_kernel<BN, MODE, CS4>), dim3((a.M + TBM - 1) / TBM, (a.N + BN - 1) / BN), dim3(256), 0, s, a);
 }
 
 // forward pass of the batch already at w.x4 (channels-last) up to the head outputs hp / hv
@@ -1875,9 +1862,7 @@ static int train_backward_enqueue(azg_handle *h, int n, const float *states, con
         g.dz = w.dz[l]; g.ldz = kTrainCout[l]; g.J = kTrainCout[l]; g.part = w.wpart[l]; g.bpart = w.bpart[l];
         g.M = M; g.S = S; g.Nb = N; g.rows_per_split = w.wrows[l];
         const dim3 grid((g.I + TBM - 1) / TBM, 1, w.wsplits[l]);
-        static const bool once = (train_allow_lds(wgrad_gemm_kernel<128>), true);
-        (void)once;
-        if (l == 2) hipLaunchKernelGGL((wgrad_gemm_kernel<128>), grid, dim3(256), train_lds_pad(), s, g);
+        if (l == 2) hipLaunchKernelGGL((wgrad_gemm_kernel<128>), grid, dim3(256), 0, s, g);
         else if (l == 1) hipLaunchKernelGGL((wgrad_gemm_kernel<64>), grid, dim3(256), 0, s, g);
         else hipLaunchKernelGGL((wgrad_gemm_kernel<32>), grid, dim3(256), 0, s, g);
         if (l > 0) {
