@@ -24,7 +24,7 @@ def _policy_from(ev, oracle, n, k):
     return policy
 
 
-@pytest.mark.parametrize("n,batch", [(8, 37), (8, 512), (6, 64), (15, 20), (11, 3)])
+@pytest.mark.parametrize("n,batch", [(8, 37), (8, 512), (6, 64), (15, 20), (11, 3), (16, 5), (7, 130)])
 def test_native_gradients_match_autograd(az, n, batch):
     """The library's float32 backward pass (azg_train_backward: implicit-GEMM convolutions on the
     float32 matrix cores, heads, fully connected layers, both losses) against the reference's loss
