@@ -334,14 +334,14 @@ static bool pick_search(int N, int mode, int cnn_mode, SearchLaunch *out)
     case 6: *out = f16 ? net_launch<6, 2, true>() : net_launch<6, 2, false>(); break;
     case 8: *out = f16 ? net_launch<8, AZG_T8, true>() : net_launch<8, 2, false>(); break;
     case 15: *out = f16 ? (AZG_DUAL ? dual_launch<15, 1>() : net_launch<15, 1, true>()) : net_launch<15, 1, false>(); break;
-    // the other board sizes: split-f16 arithmetic only
-    case 7: if (!f16) return false; *out = net_launch<7, 2, true>(); break;
-    case 9: if (!f16) return false; *out = AZG_DUAL ? dual_launch<9, 1>() : net_launch<9, 1, true>(); break;
-    case 10: if (!f16) return false; *out = AZG_DUAL ? dual_launch<10, 1>() : net_launch<10, 1, true>(); break;
-    case 11: if (!f16) return false; *out = AZG_DUAL ? dual_launch<11, 1>() : net_launch<11, 1, true>(); break;
-    case 12: if (!f16) return false; *out = AZG_DUAL ? dual_launch<12, 1>() : net_launch<12, 1, true>(); break;
-    case 13: if (!f16) return false; *out = AZG_DUAL ? dual_launch<13, 1>() : net_launch<13, 1, true>(); break;
-    case 14: if (!f16) return false; *out = AZG_DUAL ? dual_launch<14, 1>() : net_launch<14, 1, true>(); break;
+    // (16x16: split-f16 arithmetic only -- the float32 images of one leaf, 128 channels x 18 x 18 with the halo, pass the LDS)
+    case 7: *out = f16 ? net_launch<7, 2, true>() : net_launch<7, 2, false>(); break;
+    case 9: *out = f16 ? (AZG_DUAL ? dual_launch<9, 1>() : net_launch<9, 1, true>()) : net_launch<9, 1, false>(); break;
+    case 10: *out = f16 ? (AZG_DUAL ? dual_launch<10, 1>() : net_launch<10, 1, true>()) : net_launch<10, 1, false>(); break;
+    case 11: *out = f16 ? (AZG_DUAL ? dual_launch<11, 1>() : net_launch<11, 1, true>()) : net_launch<11, 1, false>(); break;
+    case 12: *out = f16 ? (AZG_DUAL ? dual_launch<12, 1>() : net_launch<12, 1, true>()) : net_launch<12, 1, false>(); break;
+    case 13: *out = f16 ? (AZG_DUAL ? dual_launch<13, 1>() : net_launch<13, 1, true>()) : net_launch<13, 1, false>(); break;
+    case 14: *out = f16 ? (AZG_DUAL ? dual_launch<14, 1>() : net_launch<14, 1, true>()) : net_launch<14, 1, false>(); break;
     case 16: if (!f16) return false; *out = net_launch<16, 1, true>(); break;
     default: return false;
     }
@@ -384,13 +384,13 @@ static bool pick_eval(int N, int cnn_mode, EvalLaunch *out)
     case 6: *out = f16 ? eval_launch<6, 2, true>() : eval_launch<6, 2, false>(); return true;
     case 8: *out = f16 ? eval_launch<8, 2, true>() : eval_launch<8, 2, false>(); return true;
     case 15: *out = f16 ? eval_launch<15, 1, true>() : eval_launch<15, 1, false>(); return true;
-    case 7: if (!f16) return false; *out = eval_launch<7, 2, true>(); return true;
-    case 9: if (!f16) return false; *out = eval_launch<9, 1, true>(); return true;
-    case 10: if (!f16) return false; *out = eval_launch<10, 1, true>(); return true;
-    case 11: if (!f16) return false; *out = eval_launch<11, 1, true>(); return true;
-    case 12: if (!f16) return false; *out = eval_launch<12, 1, true>(); return true;
-    case 13: if (!f16) return false; *out = eval_launch<13, 1, true>(); return true;
-    case 14: if (!f16) return false; *out = eval_launch<14, 1, true>(); return true;
+    case 7: *out = f16 ? eval_launch<7, 2, true>() : eval_launch<7, 2, false>(); return true;
+    case 9: *out = f16 ? eval_launch<9, 1, true>() : eval_launch<9, 1, false>(); return true;
+    case 10: *out = f16 ? eval_launch<10, 1, true>() : eval_launch<10, 1, false>(); return true;
+    case 11: *out = f16 ? eval_launch<11, 1, true>() : eval_launch<11, 1, false>(); return true;
+    case 12: *out = f16 ? eval_launch<12, 1, true>() : eval_launch<12, 1, false>(); return true;
+    case 13: *out = f16 ? eval_launch<13, 1, true>() : eval_launch<13, 1, false>(); return true;
+    case 14: *out = f16 ? eval_launch<14, 1, true>() : eval_launch<14, 1, false>(); return true;
     case 16: if (!f16) return false; *out = eval_launch<16, 1, true>(); return true;
     default: return false;
     }

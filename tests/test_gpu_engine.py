@@ -411,7 +411,7 @@ def test_error_paths(az):
     with pytest.raises(az._lib.AzgError):
         az.SelfPlayEngine(5, 5, 10, 1)                       # no CNN kernel below 6x6
     with pytest.raises(az._lib.AzgError):
-        az.SelfPlayEngine(9, 5, 10, 1, cnn_mode=az._lib.CNN_F32)   # float32 kernels exist for 6, 8, 15 only
+        az.SelfPlayEngine(16, 5, 10, 1, cnn_mode=az._lib.CNN_F32)  # float32-MFMA kernels exist for 6x6 ... 15x15 (LDS), not 16x16
     eng = az.SelfPlayEngine(8, 5, 10, 1)
     eng.reset_games()
     with pytest.raises(az._lib.AzgError) as e:
@@ -966,15 +966,16 @@ def test_full_batch_pipelined_games_equal_oracle_games_with_gpu_priors(az, oracl
     ev.close()
 
 
-@pytest.mark.parametrize("n", [6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16])
-def test_cnn_and_net_search_on_every_board_size(az, oracle, n):
+@pytest.mark.parametrize("n,cnn_mode", [(n, 0) for n in range(6, 17)] + [(n, 1) for n in (7, 9, 10, 11, 12, 13, 14)],
+                         ids=lambda v: str(v))
+def test_cnn_and_net_search_on_every_board_size(az, oracle, n, cnn_mode):
     """Split-f16 CNN kernels exist for every square board from 6x6 to 16x16 (two leaves per
-    workgroup up to 8x8, one leaf with the sparse FC above): the forward pass against the oracle's
-    float64 net (1e-5; required 1e-4), and a net-driven search bit-exact against the oracle's tree fed
-    the GPU's own outputs."""
+    workgroup up to 8x8, one leaf with the sparse FC above), float32-MFMA ones from 6x6 to 15x15 (6, 8
+    and 15 are covered by the tests above): the forward pass against the oracle's float64 net (1e-5;
+    required 1e-4), and a net-driven search bit-exact against the oracle's tree fed the GPU's own outputs."""
     k, npo = min(5, n), 48
     params = helpers.make_params(n, seed=300 + n, scale=2.0)
-    ev = az.SelfPlayEngine(n, k, 1, 1)
+    ev = az.SelfPlayEngine(n, k, 1, 1, cnn_mode=cnn_mode)
     ev.set_weights(params)
     onet = oracle.OracleNet(n, n, params, precise=True)
     for pre in helpers.random_positions(n, k, 4, seed=n):
@@ -991,7 +992,7 @@ def test_cnn_and_net_search_on_every_board_size(az, oracle, n):
         po, vo = onet.forward(ob.current_state())
         pg, vg = ev.eval_batch(ob.current_state()[None].astype(np.float32))
         assert np.abs(pg[0] - po).max() < 1e-5 and abs(vg[0] - vo) < 1e-5, n
-    eng = az.SelfPlayEngine(n, k, npo, 1)
+    eng = az.SelfPlayEngine(n, k, npo, 1, cnn_mode=cnn_mode)
     eng.set_weights(params)
     eng.reset_games()
     prefix = [(n // 2) * n + n // 2, (n // 2) * n + n // 2 + 1]
